@@ -1,0 +1,75 @@
+"""CPU: the oracle reproduces every golden vector captured from the reference.
+
+This is what pins the oracle: the fixtures under
+tests/golden/ were produced by tests/golden/make_golden.py importing the
+reference itself.  The oracle restates the same float32 algorithm, so it must
+agree far inside the 1e-4 product tolerance.
+"""
+
+import pytest
+
+import golden_cases as gc
+import radiocore_oracle as oracle
+
+# float32 rounding-order differences only (different FFT call order, FIR sums)
+ORACLE_TOL = 5e-6
+
+
+def _check(cases, tol=ORACLE_TOL):
+    bad = [(n, e) for (n, e) in cases if not e <= tol]
+    assert not bad, bad
+
+
+def test_decimate(golden):
+    _check(gc.decimate_cases(oracle, golden("decimate")))
+
+
+def test_bandpass(golden):
+    _check(gc.bandpass_cases(oracle, golden("bandpass")))
+
+
+def test_deemphasis(golden):
+    _check(gc.deemphasis_cases(oracle, golden("deemphasis")))
+
+
+def test_pll(golden):
+    _check(gc.pll_cases(oracle, golden("pll")))
+
+
+def test_fm(golden):
+    _check(gc.fm_cases(oracle, golden("fm")))
+
+
+def test_mfm(golden):
+    _check(gc.mfm_cases(oracle, golden("mfm")))
+
+
+def test_wbfm(golden):
+    _check(gc.wbfm_cases(oracle, golden("wbfm")))
+
+
+def test_wbfm_ill_conditioned(golden):
+    # rounding in z (2e-7 of peak) x conditioning (1.3e4) / decimation smoothing
+    _check(gc.wbfm_illcond_case(oracle, golden("wbfm")), tol=1e-3)
+
+
+def test_tuner_server_loop(golden):
+    _check(gc.tuner_cases(oracle, golden("tuner")))
+
+
+def test_tuner_odd(golden):
+    _check(gc.tuner_odd_cases(oracle, golden("tuner_odd")))
+
+
+def test_size_mismatch_raises():
+    import numpy as np
+    for cls in (oracle.FM, oracle.MFM, oracle.WBFM):
+        with pytest.raises(ValueError, match="input_sig size and input_size mismatch"):
+            cls(60000, 12000).run(np.zeros(59999, np.complex64))
+    with pytest.raises(ValueError):
+        oracle.Decimate(100, 10).run(np.zeros(99, np.float32))
+    with pytest.raises(IndexError):
+        t = oracle.Tuner()
+        t.add_channel(1e6, 1000, None)
+        t.load(np.zeros(1000, np.complex64))
+        t.run(3)
