@@ -1,0 +1,148 @@
+/*
+ * rcfm.h -- C ABI of librcfm.so: the MI355X (gfx950) implementation of
+ * radio-core's per-buffer DSP hot path (Tuner -> FM / MFM / WBFM).
+ *
+ * The reference (luigifcruz/radio-core v1.0.0) has no FFI: its device seam is
+ * the module swap in radiocore/_internal/injector.py:16-29 (numpy+scipy vs
+ * cupy+cusignal).  This header is what a third Injector branch binds instead
+ * (INTEGRATION.md shows the ctypes stub).  Every entry point names the
+ * reference call site(s) it replaces, relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain C types only; all data pointers are DEVICE pointers unless the
+ *     parameter name ends in _host;
+ *   - complex data is interleaved float (re, im) = numpy complex64;
+ *   - every function returns 0 on success or a negative rcfm_status;
+ *     rcfm_last_error() gives the message of the calling thread's last failure;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     are asynchronous on that stream; handles are not thread-safe (the
+ *     reference is driven by one DSP thread, examples/multi_fm_server.py:86-106);
+ *   - inputs are never modified; outputs are caller-owned; state and
+ *     workspaces are owned by the handle and released by *_destroy.
+ *   - batched arrays are channel-major and contiguous: iq [C][B] complex64,
+ *     audio [C][A][ch] float32 (ch = 1 for FM/MFM, 2 = interleaved L,R for WBFM,
+ *     the byte layout of the reference's (1, A, 2) array, wbfm.py:94).
+ */
+#ifndef RCFM_H
+#define RCFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCFM_VERSION 100 /* 0.1.0 */
+
+typedef enum rcfm_status {
+    RCFM_OK = 0,
+    RCFM_ERR_SIZE = -1,    /* -> ValueError("input_sig size and input_size mismatch") fm.py:57-58 */
+    RCFM_ERR_INDEX = -2,   /* -> IndexError (bad channel index, tuner.py:151) */
+    RCFM_ERR_RUNTIME = -3, /* HIP / rocFFT failure */
+    RCFM_ERR_ARG = -4,     /* invalid argument (NULL handle, unsupported size, ...) */
+    RCFM_ERR_STATE = -5    /* call order (tuner_run before tuner_load, tuner.py:140-161) */
+} rcfm_status;
+
+typedef enum rcfm_demod_kind {
+    RCFM_FM = 0,  /* radiocore/analog/fm.py:26-72   */
+    RCFM_MFM = 1, /* radiocore/analog/mfm.py:29-71  */
+    RCFM_WBFM = 2 /* radiocore/analog/wbfm.py:32-105 */
+} rcfm_demod_kind;
+
+typedef struct rcfm_tuner_s* rcfm_tuner_t;
+typedef struct rcfm_demod_s* rcfm_demod_t;
+typedef struct rcfm_resampler_s* rcfm_resampler_t;
+
+/* ---- library / device ---------------------------------------------------- */
+
+int rcfm_version(void);
+const char* rcfm_last_error(void);
+/* replaces radiocore.HasCuda() (radiocore/__init__.py:6-26): number of HIP devices */
+int rcfm_device_count(int* count);
+/* Plain device-memory helpers for hosts that do not bring their own allocator
+ * (replace cupy.asarray / cupy.asnumpy at tuner.py:137, fm.py:60,70). */
+int rcfm_malloc(void** dptr, size_t bytes);
+int rcfm_free(void* dptr);
+int rcfm_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
+int rcfm_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
+int rcfm_stream_sync(void* stream);
+
+/* ---- Tuner (radiocore/tools/tuner.py) ------------------------------------ */
+
+/* Tuner geometry is host-side Python in both trees (tuner.py:77-124,163-174);
+ * the device handle receives the result: n = int(input_bandwidth) wideband
+ * samples per buffer, and per channel roll[c] = int(f_in - f_c) (tuner.py:152)
+ * and bw[c] = int(bandwidth) (tuner.py:153). */
+int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_t* bw_host,
+                      rcfm_tuner_t* out);
+/* Tuner.load, tuner.py:126-138: X = FFT_n(x), kept by the handle. x: [n] complex64. */
+int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream);
+/* Tuner.run for channels [first, first+count), tuner.py:140-161: circular shift
+ * by roll, fftshifted-Hann weight, brick-wall truncation to bw bins, inverse
+ * FFT, x bw/n.  All channels of the range must share one bandwidth B;
+ * out: [count][B] complex64. */
+int rcfm_tuner_run(rcfm_tuner_t t, int first, int count, void* out, void* stream);
+/* Device pointer of the stored spectrum X [n] complex64 (Tuner._buffer). */
+int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X);
+int rcfm_tuner_destroy(rcfm_tuner_t t);
+
+/* ---- demodulators (radiocore/analog/{fm,mfm,wbfm}.py) --------------------- */
+
+/* C independent channels (or C consecutive buffers of distinct channels) of
+ * identical geometry B -> A.  tau = deemphasis rate (mfm.py:32, wbfm.py:35).
+ * chunk = channels processed per pass through the kernel chain (0 = default):
+ * intermediates of one chunk stay resident in the 256 MiB Infinity Cache. */
+int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm_demod_t* out);
+/* FM.run / MFM.run / WBFM.run on channels [first, first+count):
+ * iq [count][B] complex64 -> audio [count][A][ch] float32. */
+int rcfm_demod_run(rcfm_demod_t d, int first, int count, const void* iq, void* audio,
+                   void* stream);
+/* De-emphasis filter state, the reference's Deemphasis._state (deemphasis.py:48-49,64):
+ * [C][ch][50] float32, host memory.  reset = lfilter_zi(taps) for every channel. */
+int rcfm_demod_reset_state(rcfm_demod_t d, void* stream);
+int rcfm_demod_get_state(rcfm_demod_t d, float* state_host, void* stream);
+int rcfm_demod_set_state(rcfm_demod_t d, const float* state_host, void* stream);
+/* Design outputs for parity checks: 51 de-emphasis taps, 41 pilot band-pass taps
+ * (host, float32).  Either pointer may be NULL. */
+int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_host);
+int rcfm_demod_destroy(rcfm_demod_t d);
+
+/* Whole hot path for one wideband buffer already loaded with rcfm_tuner_load:
+ * the loop of examples/multi_fm_server.py:100-106 (run -> demodulator.run) for
+ * channels [first, first+count), chunk by chunk.  audio: [count][A][ch]. */
+int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void* audio,
+                      void* stream);
+
+/* ---- primitives (class parity with radiocore/analog) ---------------------- */
+
+/* Decimate, decimate.py:21-50 = scipy.signal.resample with the fftshifted
+ * periodic Hamming window: C signals of n samples -> m samples.
+ * is_complex = 0: float32 in/out; 1: complex64 in/out (receive_fm.py:80). */
+int rcfm_resampler_create(int C, int n, int m, int is_complex, rcfm_resampler_t* out);
+int rcfm_resampler_run(rcfm_resampler_t r, const void* in, void* out, void* stream);
+int rcfm_resampler_destroy(rcfm_resampler_t r);
+
+/* Bandpass.run, bandpass.py:59-74 = filtfilt(taps, [1], x), padtype odd:
+ * x [C][n] float32 -> y [C][n] float32; taps_host: ntaps float32 (firwin output,
+ * designed on the host in both trees, bandpass.py:50-54).  n > 3*ntaps. */
+int rcfm_filtfilt(int C, int n, const float* taps_host, int ntaps, const void* x, void* y,
+                  void* stream);
+/* Deemphasis.run, deemphasis.py:51-66 = lfilter(taps, 1, x, zi=state):
+ * x [C][n] -> y [C][n] float32; state [C][ntaps-1] float32 DEVICE, updated in place. */
+int rcfm_lfilter_fir(int C, int n, const float* taps_host, int ntaps, void* state, const void* x,
+                     void* y, void* stream);
+/* PLL.step, pll.py:25-34 = scipy.signal.hilbert: x [C][n] float32 -> z [C][n] complex64. */
+int rcfm_hilbert(int C, int n, const void* x, void* z, void* stream);
+/* PLL.real / PLL.image, pll.py:36-58: out = Re or Im of z^mult / |z^mult|;
+ * z [count] complex64 -> out [count] float32.  Integer mult in [1, 64] is multiplied
+ * out like numpy's complex power; any other mult uses the principal branch. */
+int rcfm_pll_phase(const void* z, size_t count, double mult, int want_imag, void* out,
+                   void* stream);
+/* FM discriminator, fm.py:60-65: iq [C][n] complex64 -> d [C][n] float32 (d[0] = 0). */
+int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCFM_H */

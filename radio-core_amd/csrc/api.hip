@@ -1,0 +1,629 @@
+// C ABI of librcfm.so (include/rcfm.h): handles, host-side filter / window design,
+// and the per-chunk kernel chains of Tuner.run and FM / MFM / WBFM.run.
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "fft_plan.h"
+#include "kernels.h"
+
+namespace rcfm {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// fftshift(get_window(name, n))[k]  (tuner.py:156-157, decimate.py:32-33): the periodic
+// general-cosine window a0 - (1 - a0) cos(2 pi i / n) read at i = (k - n//2) mod n.
+double shifted_window(double a0, int64_t n, int64_t k) {
+    if (n == 1) return 1.0;
+    int64_t i = (k - n / 2) % n;
+    if (i < 0) i += n;
+    return a0 - (1.0 - a0) * std::cos(2.0 * kPi * (double)i / (double)n);
+}
+
+// Device tables + scalars of one scipy.signal.resample geometry n -> m.
+struct ResampleGeom {
+    int64_t n = 0, m = 0;
+    int nmin = 0, nyq = 0, nneg = 0;
+    int nyq_mode = NYQ_NONE;   // complex
+    float w_merge = 0.f;       // complex, NYQ_DOWN
+    float nyq_factor = 1.f;    // real
+    float scale = 1.f;         // (m/n) * 1/m for an unnormalised inverse
+    DeviceBuffer wpos, wneg;   // complex: float[nyq], float[nneg + 1]
+    DeviceBuffer wr;           // real: float[nyq]
+
+    void build(int64_t n_, int64_t m_, double a0, bool complex_input) {
+        n = n_;
+        m = m_;
+        nmin = (int)std::min(n, m);
+        nyq = nmin / 2 + 1;
+        scale = (float)(1.0 / (double)n);
+        const bool even = (nmin % 2) == 0;
+        if (complex_input) {
+            nneg = nmin > 2 ? nmin - nyq : 0;
+            std::vector<float> p(nyq), q(nneg + 1, 0.f);
+            for (int k = 0; k < nyq; ++k) p[k] = (float)shifted_window(a0, n, k);
+            for (int j = 1; j <= nneg; ++j) q[j] = (float)shifted_window(a0, n, n - j);
+            wpos.upload(p.data(), p.size() * sizeof(float));
+            wneg.upload(q.data(), q.size() * sizeof(float));
+            nyq_mode = NYQ_NONE;
+            if (even && m < n && nmin > 2) {   // (for nmin == 2 scipy's slice is empty)
+                nyq_mode = NYQ_DOWN;
+                w_merge = (float)shifted_window(a0, n, n - nmin / 2);
+            } else if (even && n < m) {
+                nyq_mode = NYQ_UP;
+            }
+        } else {
+            // "Fold the window back on itself to mimic complex behavior"
+            std::vector<float> r(nyq);
+            for (int k = 0; k < nyq; ++k) {
+                double w = shifted_window(a0, n, k);
+                if (k >= 1) w = 0.5 * (w + shifted_window(a0, n, n - k));
+                r[k] = (float)w;
+            }
+            wr.upload(r.data(), r.size() * sizeof(float));
+            nyq_factor = 1.f;
+            if (even && m < n) nyq_factor = 2.f;
+            if (even && n < m) nyq_factor = 0.5f;
+        }
+    }
+};
+
+// firwin(numtaps, [lo, hi], pass_zero=False, window="hamm"), bandpass.py:50-52.
+std::vector<double> firwin_bandpass(int numtaps, double lo, double hi) {
+    std::vector<double> h(numtaps);
+    const double alpha = 0.5 * (numtaps - 1);
+    auto sinc = [](double x) { return x == 0.0 ? 1.0 : std::sin(kPi * x) / (kPi * x); };
+    const double fc = 0.5 * (lo + hi);
+    double s = 0.0;
+    for (int i = 0; i < numtaps; ++i) {
+        const double mm = i - alpha;
+        const double win = numtaps == 1 ? 1.0 : 0.54 - 0.46 * std::cos(2.0 * kPi * i / (numtaps - 1));
+        h[i] = (hi * sinc(hi * mm) - lo * sinc(lo * mm)) * win;
+        s += h[i] * std::cos(kPi * mm * fc);
+    }
+    for (auto& v : h) v /= s;
+    return h;
+}
+
+// g = b (*) reverse(b): the zero-phase kernel of filtfilt for an FIR b; returns g[centre..edge].
+std::vector<float> zero_phase_kernel(const float* b, int nb) {
+    std::vector<float> g(nb);
+    for (int lag = 0; lag < nb; ++lag) {
+        double acc = 0.0;
+        for (int i = 0; i + lag < nb; ++i) acc += (double)b[i] * (double)b[i + lag];
+        g[lag] = (float)acc;
+    }
+    return g;
+}
+
+// deemphasis.py:37-49: first 51 impulse-response samples of (1-x)/(z-x), then lfilter_zi.
+void deemphasis_design(int64_t fs, double tau, float* taps51, float* zi50) {
+    const double x = std::exp(-1.0 / ((double)fs * tau));
+    double st = 0.0, u = 1.0;
+    for (int i = 0; i < 51; ++i) {
+        taps51[i] = (float)((1.0 - x) * st);
+        st = x * st + u;
+        u = 0.0;
+    }
+    // lfilter_zi for an FIR: zi[k] = sum_{j>k} b[j]  (float32 cumulative sum from the tail)
+    float acc = 0.f;
+    for (int k = 49; k >= 0; --k) {
+        acc += taps51[k + 1];
+        zi50[k] = acc;
+    }
+}
+
+// Plans are keyed by batch size: a full chunk and (at most) one remainder.
+struct PlanCache {
+    std::map<int, std::unique_ptr<FftPlan>> by_batch;
+    FftPlan& get(FftKind kind, size_t n, int batch, bool in_place, size_t& work_need) {
+        auto it = by_batch.find(batch);
+        if (it == by_batch.end())
+            it = by_batch.emplace(batch, std::make_unique<FftPlan>(kind, n, (size_t)batch, in_place)).first;
+        work_need = std::max(work_need, it->second->work_bytes());
+        return *it->second;
+    }
+};
+
+}  // namespace
+}  // namespace rcfm
+
+using namespace rcfm;
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+
+struct rcfm_tuner_s {
+    int64_t n = 0;
+    int nch = 0;
+    std::vector<int64_t> roll;   // normalised to [0, n)
+    std::vector<int32_t> bw;
+    DeviceBuffer roll_dev;
+    DeviceBuffer X;
+    DeviceBuffer work;
+    std::unique_ptr<FftPlan> forward;
+    bool loaded = false;
+    struct Band {
+        ResampleGeom geom;
+        PlanCache inverse;
+    };
+    std::map<int32_t, std::unique_ptr<Band>> bands;
+
+    Band& band(int32_t b) {
+        auto it = bands.find(b);
+        if (it == bands.end()) {
+            auto nb = std::make_unique<Band>();
+            nb->geom.build(n, b, 0.5 /* hann */, true);
+            it = bands.emplace(b, std::move(nb)).first;
+        }
+        return *it->second;
+    }
+
+    void run(int first, int count, float2* out, hipStream_t s) {
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
+        RC_REQUIRE(loaded, RCFM_ERR_STATE, "rcfm_tuner_run called before rcfm_tuner_load");
+        if (count == 0) return;
+        const int32_t B = bw[first];
+        for (int i = 0; i < count; ++i)
+            RC_REQUIRE(bw[first + i] == B, RCFM_ERR_ARG, "channels of one rcfm_tuner_run range must share a bandwidth");
+        Band& bd = band(B);
+        size_t need = 0;
+        FftPlan& inv = bd.inverse.get(FftKind::C2C_INVERSE, (size_t)B, count, true, need);
+        work.reserve(need);
+        const ResampleGeom& g = bd.geom;
+        launch_spectrum_c2c(X.as<float2>(), 0, n, roll_dev.as<int64_t>() + first, out, B, count,
+                            g.wpos.as<float>(), g.wneg.as<float>(), g.w_merge, g.nyq, g.nneg, g.nyq_mode,
+                            g.scale, s);
+        inv.exec(out, out, work.get(), s);
+    }
+};
+
+struct rcfm_demod_s {
+    int kind = 0, C = 0, B = 0, A = 0, ch = 1, chunk = 1;
+    double tau = 75e-6;
+    float taps_h[51];
+    float zi_h[50];
+    float pilot_h[41];
+    DeviceBuffer taps, pilot_g, state;
+    float side_tap = 0.23f;
+    ResampleGeom geom;   // B -> A, real, Hamming
+    PlanCache r2c_B, c2c_inv_B, c2c_fwd_B, c2c_inv_A, c2r_A;
+    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial;
+    int tiles = 0;
+
+    void alloc() {
+        const size_t c = (size_t)chunk;
+        tiles = fir_tiles(A);
+        if (kind == RCFM_WBFM) {
+            buf_m.reset(c * B * sizeof(float));
+            buf_p.reset(c * B * sizeof(float));
+            buf_P.reset(c * (B / 2 + 1) * sizeof(float2));
+            buf_Z.reset(c * B * sizeof(float2));      // analytic pilot, then the packed L/R signal
+            buf_V.reset(c * A * sizeof(float2));      // packed audio spectrum -> l + j r
+        } else {
+            buf_m.reset(c * B * sizeof(float));                    // discriminator output
+            buf_P.reset(c * (B / 2 + 1) * sizeof(float2));          // its half spectrum
+            buf_V.reset(c * (A / 2 + 1) * sizeof(float2));          // resampled half spectrum
+            if (kind == RCFM_MFM) buf_v.reset(c * A * sizeof(float));
+        }
+        if (kind != RCFM_FM) partial.reset((size_t)chunk * ch * tiles * sizeof(float));
+    }
+
+    void reset_state(hipStream_t s) {
+        if (kind == RCFM_FM) return;
+        std::vector<float> all((size_t)C * ch * 50);
+        for (size_t i = 0; i < all.size(); ++i) all[i] = zi_h[i % 50];
+        RC_HIP(hipMemcpyAsync(state.get(), all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        RC_HIP(hipStreamSynchronize(s));
+    }
+
+    void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s) {
+        size_t need = 0;
+        if (kind == RCFM_WBFM) {
+            FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);
+            FftPlan& f2 = c2c_inv_B.get(FftKind::C2C_INVERSE, B, cnt, true, need);
+            FftPlan& f3 = c2c_fwd_B.get(FftKind::C2C_FORWARD, B, cnt, true, need);
+            FftPlan& f4 = c2c_inv_A.get(FftKind::C2C_INVERSE, A, cnt, true, need);
+            work.reserve(need);
+            float* m = buf_m.as<float>();
+            float* p = buf_p.as<float>();
+            float2* P = buf_P.as<float2>();
+            float2* Z = buf_Z.as<float2>();
+            float2* V = buf_V.as<float2>();
+            // wbfm.py:77-80  FM(B->B) and the pilot band-pass
+            launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
+            // wbfm.py:80 / pll.py:34  analytic signal of the pilot
+            f1.exec(p, P, work.get(), s);
+            launch_hilbert_mask(P, Z, B, cnt, 1.0f / (float)B, s);
+            f2.exec(Z, Z, work.get(), s);
+            // wbfm.py:83,86-87  38 kHz carrier, L-R, stereo matrix; both legs packed in one complex signal
+            launch_stereo_mix(Z, m, Z, (size_t)cnt * B, s);
+            f3.exec(Z, Z, work.get(), s);
+            launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin, geom.nyq_factor,
+                                 geom.scale, s);
+            f4.exec(V, V, work.get(), s);   // -> [cnt][A][2] float32, L/R interleaved
+            // wbfm.py:90-100  de-emphasis (separate L/R state), joint DC removal, clip
+            float* st = state.as<float>() + (size_t)first * ch * 50;
+            launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
+                       partial.as<float>(), s);
+            launch_fir_state(reinterpret_cast<float*>(V), A, 2, cnt, taps.as<float>(), 51, st, s);
+            launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles, s);
+            return;
+        }
+        FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);
+        FftPlan& f2 = c2r_A.get(FftKind::C2R, A, cnt, false, need);
+        work.reserve(need);
+        float* d = buf_m.as<float>();
+        float2* D = buf_P.as<float2>();
+        float2* Y = buf_V.as<float2>();
+        // fm.py:60-66  discriminator, then Decimate(B -> A)
+        launch_discriminator(iq, d, B, cnt, s);
+        f1.exec(d, D, work.get(), s);
+        launch_spectrum_r2c(D, B, Y, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin, geom.nyq_factor, geom.scale, s);
+        if (kind == RCFM_FM) {
+            f2.exec(Y, audio, work.get(), s);
+            return;
+        }
+        float* v = buf_v.as<float>();
+        f2.exec(Y, v, work.get(), s);
+        // mfm.py:63-65
+        float* st = state.as<float>() + (size_t)first * 50;
+        launch_fir(v, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
+        launch_fir_state(v, A, 1, cnt, taps.as<float>(), 51, st, s);
+        launch_dc_clip(audio, A, 1, cnt, partial.as<float>(), tiles, s);
+    }
+};
+
+struct rcfm_resampler_s {
+    int C = 0;
+    int64_t n = 0, m = 0;
+    bool cplx = false;
+    ResampleGeom geom;
+    std::unique_ptr<FftPlan> fwd, inv;
+    DeviceBuffer spec_in, spec_out, work;
+};
+
+// ---------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+int rcfm_version(void) { return RCFM_VERSION; }
+
+const char* rcfm_last_error(void) { return g_last_error.c_str(); }
+
+int rcfm_device_count(int* count) {
+    return guarded([&] {
+        RC_REQUIRE(count != nullptr, RCFM_ERR_ARG, "count is NULL");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        *count = (e == hipSuccess) ? n : 0;
+        if (e != hipSuccess) (void)hipGetLastError();
+    });
+}
+
+int rcfm_malloc(void** dptr, size_t bytes) {
+    return guarded([&] {
+        RC_REQUIRE(dptr != nullptr, RCFM_ERR_ARG, "dptr is NULL");
+        RC_HIP(hipMalloc(dptr, bytes));
+    });
+}
+
+int rcfm_free(void* dptr) {
+    return guarded([&] { RC_HIP(hipFree(dptr)); });
+}
+
+int rcfm_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream) {
+    return guarded([&] { RC_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream))); });
+}
+
+int rcfm_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream) {
+    return guarded([&] { RC_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream))); });
+}
+
+int rcfm_stream_sync(void* stream) {
+    return guarded([&] { RC_HIP(hipStreamSynchronize(as_stream(stream))); });
+}
+
+// ---- tuner -----------------------------------------------------------------
+
+int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_t* bw_host, rcfm_tuner_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out != nullptr, RCFM_ERR_ARG, "out is NULL");
+        RC_REQUIRE(n >= 1 && nch >= 0, RCFM_ERR_ARG, "bad tuner size");
+        RC_REQUIRE(nch == 0 || (roll_host && bw_host), RCFM_ERR_ARG, "roll/bw is NULL");
+        auto t = std::make_unique<rcfm_tuner_s>();
+        t->n = n;
+        t->nch = nch;
+        t->roll.resize(nch);
+        t->bw.assign(bw_host, bw_host + nch);
+        for (int i = 0; i < nch; ++i) {
+            RC_REQUIRE(bw_host[i] >= 1, RCFM_ERR_ARG, "channel bandwidth must be >= 1");
+            // scipy.signal.resample(domain="freq") also up-samples; the Tuner never does
+            RC_REQUIRE(bw_host[i] <= n, RCFM_ERR_ARG, "channel bandwidth exceeds the input bandwidth");
+            int64_t r = roll_host[i] % n;
+            if (r < 0) r += n;
+            t->roll[i] = r;
+        }
+        if (nch) t->roll_dev.upload(t->roll.data(), sizeof(int64_t) * nch);
+        t->X.reset(sizeof(float2) * (size_t)n);
+        t->forward = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, 1, false);
+        t->work.reserve(t->forward->work_bytes());
+        *out = t.release();
+    });
+}
+
+int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(t && x, RCFM_ERR_ARG, "NULL argument");
+        t->work.reserve(t->forward->work_bytes());
+        t->forward->exec(const_cast<void*>(x), t->X.get(), t->work.get(), as_stream(stream));
+        t->loaded = true;
+    });
+}
+
+int rcfm_tuner_run(rcfm_tuner_t t, int first, int count, void* out, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(t && out, RCFM_ERR_ARG, "NULL argument");
+        t->run(first, count, static_cast<float2*>(out), as_stream(stream));
+    });
+}
+
+int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X) {
+    return guarded([&] {
+        RC_REQUIRE(t && X, RCFM_ERR_ARG, "NULL argument");
+        *X = t->X.get();
+    });
+}
+
+int rcfm_tuner_destroy(rcfm_tuner_t t) {
+    return guarded([&] { delete t; });
+}
+
+// ---- demodulators ------------------------------------------------------------
+
+int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm_demod_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out != nullptr, RCFM_ERR_ARG, "out is NULL");
+        RC_REQUIRE(kind >= RCFM_FM && kind <= RCFM_WBFM, RCFM_ERR_ARG, "unknown demodulator kind");
+        RC_REQUIRE(C >= 1 && B >= 2 && A >= 1, RCFM_ERR_ARG, "bad demodulator size");
+        auto d = std::make_unique<rcfm_demod_s>();
+        d->kind = kind;
+        d->C = C;
+        d->B = B;
+        d->A = A;
+        d->tau = tau;
+        d->ch = (kind == RCFM_WBFM) ? 2 : 1;
+        if (chunk <= 0) {
+            const char* e = std::getenv("RCFM_CHUNK");
+            chunk = e ? std::atoi(e) : 16;
+            if (chunk <= 0) chunk = 16;
+        }
+        d->chunk = std::min(chunk, C);
+        d->geom.build(B, A, 0.54 /* hamm */, false);
+        std::memset(d->pilot_h, 0, sizeof(d->pilot_h));
+        if (kind == RCFM_WBFM) {
+            // wbfm.py:45-46: Bandpass(B, 19e3-50, 19e3+50, num_taps=41); cut-offs relative to Nyquist
+            const double nyq = 0.5 * (double)B;
+            const double lo = (19e3 - 50) / nyq, hi = (19e3 + 50) / nyq;
+            RC_REQUIRE(hi < 1.0, RCFM_ERR_ARG, "Invalid cutoff frequency: frequencies must be greater than 0 and less than fs/2.");
+            RC_REQUIRE(B > 3 * 41, RCFM_ERR_ARG, "The length of the input vector x must be greater than padlen, which is 123.");
+            auto h = firwin_bandpass(41, lo, hi);
+            for (int i = 0; i < 41; ++i) d->pilot_h[i] = (float)h[i];
+            auto g = zero_phase_kernel(d->pilot_h, 41);
+            d->pilot_g.upload(g.data(), g.size() * sizeof(float));
+            d->side_tap = (B % 2) ? (float)(0.23 * std::cos(kPi / (double)B)) : 0.23f;
+        }
+        if (kind != RCFM_FM) {
+            deemphasis_design(A, tau, d->taps_h, d->zi_h);
+            d->taps.upload(d->taps_h, sizeof(d->taps_h));
+            d->state.reset((size_t)C * d->ch * 50 * sizeof(float));
+            d->reset_state(nullptr);
+        }
+        d->alloc();
+        *out = d.release();
+    });
+}
+
+int rcfm_demod_run(rcfm_demod_t d, int first, int count, const void* iq, void* audio, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(d && iq && audio, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= d->C, RCFM_ERR_INDEX, "channel index out of range");
+        const float2* in = static_cast<const float2*>(iq);
+        float* outp = static_cast<float*>(audio);
+        for (int off = 0; off < count; off += d->chunk) {
+            const int cnt = std::min(d->chunk, count - off);
+            d->run_chunk(first + off, cnt, in + (size_t)off * d->B, outp + (size_t)off * d->A * d->ch,
+                         as_stream(stream));
+        }
+    });
+}
+
+int rcfm_demod_reset_state(rcfm_demod_t d, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");
+        d->reset_state(as_stream(stream));
+    });
+}
+
+int rcfm_demod_get_state(rcfm_demod_t d, float* state_host, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(d && state_host, RCFM_ERR_ARG, "NULL argument");
+        if (d->kind == RCFM_FM) return;
+        RC_HIP(hipMemcpyAsync(state_host, d->state.get(), (size_t)d->C * d->ch * 50 * sizeof(float),
+                              hipMemcpyDeviceToHost, as_stream(stream)));
+        RC_HIP(hipStreamSynchronize(as_stream(stream)));
+    });
+}
+
+int rcfm_demod_set_state(rcfm_demod_t d, const float* state_host, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(d && state_host, RCFM_ERR_ARG, "NULL argument");
+        if (d->kind == RCFM_FM) return;
+        RC_HIP(hipMemcpyAsync(d->state.get(), state_host, (size_t)d->C * d->ch * 50 * sizeof(float),
+                              hipMemcpyHostToDevice, as_stream(stream)));
+        RC_HIP(hipStreamSynchronize(as_stream(stream)));
+    });
+}
+
+int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_host) {
+    return guarded([&] {
+        RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");
+        if (deemph51_host) std::memcpy(deemph51_host, d->taps_h, sizeof(d->taps_h));
+        if (pilot41_host) std::memcpy(pilot41_host, d->pilot_h, sizeof(d->pilot_h));
+    });
+}
+
+int rcfm_demod_destroy(rcfm_demod_t d) {
+    return guarded([&] { delete d; });
+}
+
+int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void* audio, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(t && d && audio, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= t->nch && first + count <= d->C, RCFM_ERR_INDEX,
+                   "channel index out of range");
+        d->buf_iq.reserve((size_t)d->chunk * d->B * sizeof(float2));
+        float* outp = static_cast<float*>(audio);
+        for (int off = 0; off < count; off += d->chunk) {
+            const int cnt = std::min(d->chunk, count - off);
+            RC_REQUIRE(t->bw[first + off] == d->B, RCFM_ERR_SIZE, "input_sig size and input_size mismatch");
+            t->run(first + off, cnt, d->buf_iq.as<float2>(), as_stream(stream));
+            d->run_chunk(first + off, cnt, d->buf_iq.as<float2>(), outp + (size_t)off * d->A * d->ch,
+                         as_stream(stream));
+        }
+    });
+}
+
+// ---- primitives --------------------------------------------------------------
+
+int rcfm_resampler_create(int C, int n, int m, int is_complex, rcfm_resampler_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out != nullptr, RCFM_ERR_ARG, "out is NULL");
+        RC_REQUIRE(C >= 1 && n >= 1 && m >= 1, RCFM_ERR_ARG, "bad resampler size");
+        auto r = std::make_unique<rcfm_resampler_s>();
+        r->C = C;
+        r->n = n;
+        r->m = m;
+        r->cplx = is_complex != 0;
+        r->geom.build(n, m, 0.54, r->cplx);
+        if (r->cplx) {
+            r->fwd = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, (size_t)C, false);
+            r->inv = std::make_unique<FftPlan>(FftKind::C2C_INVERSE, (size_t)m, (size_t)C, true);
+            r->spec_in.reset((size_t)C * n * sizeof(float2));
+        } else {
+            r->fwd = std::make_unique<FftPlan>(FftKind::R2C, (size_t)n, (size_t)C, false);
+            r->inv = std::make_unique<FftPlan>(FftKind::C2R, (size_t)m, (size_t)C, false);
+            r->spec_in.reset((size_t)C * (n / 2 + 1) * sizeof(float2));
+            r->spec_out.reset((size_t)C * (m / 2 + 1) * sizeof(float2));
+        }
+        r->work.reserve(std::max(r->fwd->work_bytes(), r->inv->work_bytes()));
+        *out = r.release();
+    });
+}
+
+int rcfm_resampler_run(rcfm_resampler_t r, const void* in, void* out, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(r && in && out, RCFM_ERR_ARG, "NULL argument");
+        hipStream_t s = as_stream(stream);
+        const ResampleGeom& g = r->geom;
+        if (r->cplx) {
+            r->fwd->exec(const_cast<void*>(in), r->spec_in.get(), r->work.get(), s);
+            launch_spectrum_c2c(r->spec_in.as<float2>(), r->n, r->n, nullptr, static_cast<float2*>(out), r->m,
+                                r->C, g.wpos.as<float>(), g.wneg.as<float>(), g.w_merge, g.nyq, g.nneg,
+                                g.nyq_mode, g.scale, s);
+            r->inv->exec(out, out, r->work.get(), s);
+        } else {
+            r->fwd->exec(const_cast<void*>(in), r->spec_in.get(), r->work.get(), s);
+            launch_spectrum_r2c(r->spec_in.as<float2>(), r->n, r->spec_out.as<float2>(), r->m, r->C,
+                                g.wr.as<float>(), g.nyq, g.nmin, g.nyq_factor, g.scale, s);
+            r->inv->exec(r->spec_out.get(), out, r->work.get(), s);
+        }
+    });
+}
+
+int rcfm_resampler_destroy(rcfm_resampler_t r) {
+    return guarded([&] { delete r; });
+}
+
+int rcfm_filtfilt(int C, int n, const float* taps_host, int ntaps, const void* x, void* y, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(taps_host && x && y, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(C >= 1 && ntaps >= 1, RCFM_ERR_ARG, "bad filtfilt size");
+        RC_REQUIRE(n > 3 * ntaps, RCFM_ERR_ARG,
+                   "The length of the input vector x must be greater than padlen, which is " +
+                       std::to_string(3 * ntaps) + ".");
+        hipStream_t s = as_stream(stream);
+        auto g = zero_phase_kernel(taps_host, ntaps);
+        DeviceBuffer gd;
+        gd.upload(g.data(), g.size() * sizeof(float));
+        launch_pilot_stage(nullptr, static_cast<const float*>(x), nullptr, static_cast<float*>(y), n, C,
+                           gd.as<float>(), ntaps - 1, 0.f, s);
+        RC_HIP(hipStreamSynchronize(s));   // gd is released on return
+    });
+}
+
+int rcfm_lfilter_fir(int C, int n, const float* taps_host, int ntaps, void* state, const void* x, void* y,
+                     void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(taps_host && x && y && (state || ntaps < 2), RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(C >= 1 && n >= 1 && ntaps >= 1, RCFM_ERR_ARG, "bad lfilter size");
+        hipStream_t s = as_stream(stream);
+        DeviceBuffer td;
+        td.upload(taps_host, (size_t)ntaps * sizeof(float));
+        launch_fir(static_cast<const float*>(x), static_cast<float*>(y), n, 1, C, td.as<float>(), ntaps,
+                   static_cast<const float*>(state), nullptr, s);
+        launch_fir_state(static_cast<const float*>(x), n, 1, C, td.as<float>(), ntaps,
+                         static_cast<float*>(state), s);
+        RC_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rcfm_hilbert(int C, int n, const void* x, void* z, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(x && z, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(C >= 1 && n >= 1, RCFM_ERR_ARG, "bad hilbert size");
+        hipStream_t s = as_stream(stream);
+        FftPlan fwd(FftKind::R2C, (size_t)n, (size_t)C, false);
+        FftPlan inv(FftKind::C2C_INVERSE, (size_t)n, (size_t)C, true);
+        DeviceBuffer P((size_t)C * (n / 2 + 1) * sizeof(float2));
+        DeviceBuffer work(std::max(fwd.work_bytes(), inv.work_bytes()));
+        fwd.exec(const_cast<void*>(x), P.get(), work.get(), s);
+        launch_hilbert_mask(P.as<float2>(), static_cast<float2*>(z), n, C, 1.0f / (float)n, s);
+        inv.exec(z, z, work.get(), s);
+        RC_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rcfm_pll_phase(const void* z, size_t count, double mult, int want_imag, void* out, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(z && out, RCFM_ERR_ARG, "NULL argument");
+        launch_pll_phase(static_cast<const float2*>(z), count, mult, want_imag, static_cast<float*>(out),
+                         as_stream(stream));
+    });
+}
+
+int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(iq && d, RCFM_ERR_ARG, "NULL argument");
+        launch_discriminator(static_cast<const float2*>(iq), static_cast<float*>(d), n, C, as_stream(stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal helpers shared by the librcfm translation units (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <exception>
+#include <string>
+
+#include "rcfm.h"
+
+namespace rcfm {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+void set_last_error(const std::string& msg);
+
+#define RC_HIP(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t rc_e_ = (expr);                                                       \
+        if (rc_e_ != hipSuccess)                                                         \
+            throw ::rcfm::Error{RCFM_ERR_RUNTIME,                                        \
+                                std::string(#expr) + ": " + hipGetErrorString(rc_e_)};   \
+    } while (0)
+
+#define RC_REQUIRE(cond, code, text)                      \
+    do {                                                  \
+        if (!(cond)) throw ::rcfm::Error{(code), (text)}; \
+    } while (0)
+
+// Every extern "C" entry point runs its body through this: exceptions never
+// cross the ABI, the message is kept for rcfm_last_error().
+template <class F>
+int guarded(F&& body) {
+    try {
+        body();
+        return RCFM_OK;
+    } catch (const Error& e) {
+        set_last_error(e.msg);
+        return e.code;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return RCFM_ERR_RUNTIME;
+    } catch (...) {
+        set_last_error("unknown failure");
+        return RCFM_ERR_RUNTIME;
+    }
+}
+
+// Owning device allocation (handles own their workspaces; freed on destroy).
+class DeviceBuffer {
+   public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes) { reset(bytes); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+        if (this != &o) {
+            release();
+            p_ = o.p_;
+            bytes_ = o.bytes_;
+            o.p_ = nullptr;
+            o.bytes_ = 0;
+        }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    void reset(size_t bytes) {
+        release();
+        if (bytes) {
+            RC_HIP(hipMalloc(&p_, bytes));
+            bytes_ = bytes;
+        }
+    }
+    // grow-only
+    void reserve(size_t bytes) {
+        if (bytes > bytes_) reset(bytes);
+    }
+    void upload(const void* host, size_t bytes) {
+        reserve(bytes);
+        if (bytes) RC_HIP(hipMemcpy(p_, host, bytes, hipMemcpyHostToDevice));
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p_);
+    }
+    void* get() const { return p_; }
+    size_t bytes() const { return bytes_; }
+
+   private:
+    void release() {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        bytes_ = 0;
+    }
+    void* p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace rcfm

@@ -1,0 +1,453 @@
+// Hand-written gfx950 kernels of the Tuner -> FM / MFM / WBFM path.
+//
+// Everything here is HBM/L2-streaming work (no dense contraction, so no MFMA):
+// one thread per output element with coalesced 4/8-byte accesses, LDS tiles with
+// halos for the two FIR stages, wave64 shuffle reductions for the DC sums.
+// Reference call sites are cited per kernel; the algebra (closed forms of the
+// scipy calls) is derived in DESIGN.md and pinned by tests/test_oracle_scipy.py.
+
+#include "kernels.h"
+
+namespace rcfm {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kInvPi = 0.31830988618379067154f;
+
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+inline dim3 grid2(int64_t items, int per_block, int batch) {
+    return dim3((unsigned)((items + per_block - 1) / per_block), (unsigned)batch, 1);
+}
+
+// ---------------------------------------------------------------------------
+// Spectral resampling (scipy.signal.resample, spectrum side)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kThreads) void k_spectrum_c2c(
+    const float2* __restrict__ X, int64_t x_stride, int64_t n, const int64_t* __restrict__ roll,
+    float2* __restrict__ Y, int64_t m, const float* __restrict__ wpos, const float* __restrict__ wneg,
+    float w_merge, int nyq, int nneg, int nyq_mode, float scale) {
+    const int c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= m) return;
+    const float2* Xc = X + (int64_t)c * x_stride;
+    const int64_t r = roll ? roll[c] : 0;
+    // np.roll(X, r)[src] == X[(src - r) mod n]            (tuner.py:159)
+    auto fetch = [&](int64_t src) {
+        int64_t i = src - r;
+        if (i < 0) i += n;
+        return Xc[i];
+    };
+    const int64_t half = nyq - 1;  // min(n, m) / 2
+    float2 y = make_float2(0.f, 0.f);
+    if (k < nyq) {
+        y = cscale(fetch(k), wpos[k]);
+        if (k == half && nyq_mode == NYQ_DOWN) {  // Y[+N/2] += X[-N/2]
+            float2 v = cscale(fetch(n - half), w_merge);
+            y.x += v.x;
+            y.y += v.y;
+        } else if (k == half && nyq_mode == NYQ_UP) {
+            y = cscale(y, 0.5f);
+        }
+    } else {
+        const int64_t j = m - k;
+        if (j <= nneg) {
+            y = cscale(fetch(n - j), wneg[j]);
+        } else if (nyq_mode == NYQ_UP && j == half) {  // Y[-N/2] = Y[+N/2]
+            y = cscale(fetch(half), 0.5f * wpos[half]);
+        }
+    }
+    Y[(int64_t)c * m + k] = cscale(y, scale);
+}
+
+__global__ __launch_bounds__(kThreads) void k_spectrum_r2c(const float2* __restrict__ X, int64_t n,
+                                                           float2* __restrict__ Y, int64_t m,
+                                                           const float* __restrict__ wr, int nyq, int nmin,
+                                                           float nyq_factor, float scale) {
+    const int c = blockIdx.y;
+    const int64_t mh = m / 2 + 1;
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= mh) return;
+    float2 y = make_float2(0.f, 0.f);
+    if (k < nyq) {
+        y = cscale(X[(int64_t)c * (n / 2 + 1) + k], wr[k]);
+        if ((nmin & 1) == 0 && k == nmin / 2) y = cscale(y, nyq_factor);
+    }
+    // A real inverse transform never sees the imaginary part of DC / Nyquist
+    // (pocketfft's c2r drops it); make that explicit for any backend.
+    if (k == 0 || ((m & 1) == 0 && k == m / 2)) y.y = 0.f;
+    Y[(int64_t)c * mh + k] = cscale(y, scale);
+}
+
+__global__ __launch_bounds__(kThreads) void k_hilbert_mask(const float2* __restrict__ P,
+                                                           float2* __restrict__ Z, int64_t n, float scale) {
+    const int c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= n) return;
+    const float2* Pc = P + (int64_t)c * (n / 2 + 1);
+    float2 v = make_float2(0.f, 0.f);
+    if (k == 0) {
+        v = Pc[0];
+    } else if (k < (n + 1) / 2) {
+        v = cscale(Pc[k], 2.f);
+    } else if ((n & 1) == 0 && k == n / 2) {
+        v = Pc[k];
+    }
+    Z[(int64_t)c * n + k] = cscale(v, scale);
+}
+
+__global__ __launch_bounds__(kThreads) void k_stereo_unpack(const float2* __restrict__ U, int64_t B,
+                                                            float2* __restrict__ V, int64_t A,
+                                                            const float* __restrict__ wr, int nyq, int nmin,
+                                                            float nyq_factor, float scale) {
+    const int c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= A) return;
+    const float2* Uc = U + (int64_t)c * B;
+    const bool mirrored = k > A / 2;
+    const int64_t kk = mirrored ? A - k : k;
+    float2 hl = make_float2(0.f, 0.f), hr = make_float2(0.f, 0.f);
+    if (kk < nyq) {
+        // u = l + j r with l, r real  =>  L[k] = (U[k] + conj U[-k]) / 2,  R[k] = (U[k] - conj U[-k]) / 2j
+        const float2 a = Uc[kk];
+        const float2 b = Uc[kk == 0 ? 0 : B - kk];
+        float w = wr[kk] * scale;
+        if ((nmin & 1) == 0 && kk == nmin / 2) w *= nyq_factor;
+        hl = make_float2(0.5f * (a.x + b.x) * w, 0.5f * (a.y - b.y) * w);
+        hr = make_float2(0.5f * (a.y + b.y) * w, -0.5f * (a.x - b.x) * w);
+        if (kk == 0 || ((A & 1) == 0 && kk == A / 2)) {
+            hl.y = 0.f;
+            hr.y = 0.f;
+        }
+    }
+    if (mirrored) {
+        hl.y = -hl.y;
+        hr.y = -hr.y;
+    }
+    // packed Hermitian pair: V = HL + j HR  ->  ifft(V) = l + j r
+    V[(int64_t)c * A + k] = make_float2(hl.x - hr.y, hl.y + hr.x);
+}
+
+// ---------------------------------------------------------------------------
+// Discriminator and the fused WBFM front end
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float phase_step(float2 a, float2 b) {
+    // arg(a conj(b)) / pi == diff(unwrap(angle(x))) / pi without the float32 unwrap noise
+    return atan2f(a.y * b.x - a.x * b.y, a.x * b.x + a.y * b.y) * kInvPi;
+}
+
+__global__ __launch_bounds__(kThreads) void k_discriminator(const float2* __restrict__ iq,
+                                                            float* __restrict__ d, int64_t n) {
+    const int c = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float2* xc = iq + (int64_t)c * n;
+    d[(int64_t)c * n + i] = (i == 0) ? 0.f : phase_step(xc[i], xc[i - 1]);
+}
+
+constexpr int kPilotTile = 1024;
+
+__global__ __launch_bounds__(kThreads) void k_pilot_stage(const float2* __restrict__ iq,
+                                                          const float* __restrict__ x,
+                                                          float* __restrict__ m_out,
+                                                          float* __restrict__ p_out, int64_t n,
+                                                          const float* __restrict__ g, int H, float side_tap) {
+    constexpr int T = kPilotTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g_s = smem;                 // H + 1 taps, g_s[0] = centre
+    float* m_s = g_s + (H + 1);        // T + 2H  : m[q0 + s]
+    float* d_s = m_s + (T + 2 * H);    // T + 2H + 2 : d[q0 - 1 + s] (circular)
+    const int c = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * T;
+    const int64_t q0 = t0 - H;
+    for (int i = tid; i <= H; i += kThreads) g_s[i] = g[i];
+
+    if (iq != nullptr) {
+        const float2* xc = iq + (int64_t)c * n;
+        for (int s = tid; s < T + 2 * H + 2; s += kThreads) {
+            int64_t i = q0 - 1 + s;
+            float v = 0.f;
+            if (i >= -1 && i <= n) {
+                if (i == -1) i = n - 1;   // the same-size Decimate is circular (decimate.py:48)
+                if (i == n) i = 0;
+                if (i > 0) v = phase_step(xc[i], xc[i - 1]);   // d[0] = 0 (fm.py:64)
+            }
+            d_s[s] = v;
+        }
+        __syncthreads();
+        for (int s = tid; s < T + 2 * H; s += kThreads) {
+            const int64_t q = q0 + s;
+            float v = 0.f;
+            if (q >= 0 && q < n) {
+                v = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
+                if (q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
+            }
+            m_s[s] = v;
+        }
+    } else {
+        const float* xc = x + (int64_t)c * n;
+        for (int s = tid; s < T + 2 * H; s += kThreads) {
+            const int64_t q = q0 + s;
+            m_s[s] = (q >= 0 && q < n) ? xc[q] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // filtfilt(b, 1, m) == sum_j g[|j|] e[i + j], e = m odd-extended at both ends.
+    const int64_t last = n - 1;
+    for (int o = tid; o < T; o += kThreads) {
+        const int64_t i = t0 + o;
+        if (i >= n) break;
+        const int base = o + H;
+        float acc = g_s[0] * m_s[base];
+        if (i - H >= 0 && i + H <= last) {
+            for (int j = 1; j <= H; ++j) acc = fmaf(g_s[j], m_s[base - j] + m_s[base + j], acc);
+        } else {
+            const float m_first = (q0 <= 0) ? m_s[0 - q0] : 0.f;
+            const float m_last = (last - q0 < T + 2 * H) ? m_s[last - q0] : 0.f;
+            for (int j = 1; j <= H; ++j) {
+                const int64_t ql = i - j, qr = i + j;
+                const float el = (ql < 0) ? 2.f * m_first - m_s[-ql - q0] : m_s[ql - q0];
+                const float er = (qr > last) ? 2.f * m_last - m_s[2 * last - qr - q0] : m_s[qr - q0];
+                acc = fmaf(g_s[j], el + er, acc);
+            }
+        }
+        p_out[(int64_t)c * n + i] = acc;
+    }
+}
+
+// z and u may be the same buffer (element i only depends on element i).
+__global__ __launch_bounds__(kThreads) void k_stereo_mix(const float2* z, const float* __restrict__ m,
+                                                         float2* u, size_t count) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= count) return;
+    const float2 v = z[i];
+    // Im(z^2) / |z^2| = 2ab / (a^2 + b^2); pre-scaled so tiny pilots do not underflow.
+    // z == 0 gives 0/0 = NaN exactly like pll.py:57-58.
+    const float s = fmaxf(fabsf(v.x), fabsf(v.y));
+    const float a = v.x / s, b = v.y / s;
+    const float s2 = (2.f * a * b) / (a * a + b * b);
+    const float mm = m[i];
+    const float lmr = (s2 * mm) * 1.0175f;
+    u[i] = make_float2(mm + lmr, mm - lmr);
+}
+
+__global__ __launch_bounds__(kThreads) void k_pll_phase(const float2* __restrict__ z, size_t count,
+                                                        double mult, int int_power, int want_imag,
+                                                        float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= count) return;
+    const float2 v = z[i];
+    if (int_power >= 1) {
+        // numpy's complex power multiplies out small integer exponents
+        float2 w = v;
+        for (int k = 1; k < int_power; ++k) w = make_float2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
+        const float mag = hypotf(w.x, w.y);
+        out[i] = (want_imag ? w.y : w.x) / mag;
+    } else {
+        const double th = mult * atan2((double)v.y, (double)v.x);
+        const bool zero = (v.x == 0.f && v.y == 0.f);
+        const double r = want_imag ? sin(th) : cos(th);
+        out[i] = zero ? __builtin_nanf("") : (float)r;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// De-emphasis FIR, DC removal, clip
+// ---------------------------------------------------------------------------
+
+constexpr int kFirTile = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kThreads / 64; ++w) t += scratch[w];
+    return t;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(kThreads) void k_fir(const float* __restrict__ x, float* __restrict__ y,
+                                                  int64_t n, int ch, const float* __restrict__ taps, int nb,
+                                                  const float* __restrict__ state,
+                                                  float* __restrict__ partial) {
+    constexpr int T = kFirTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* b_s = smem;            // nb
+    float* x_s = b_s + nb;        // T + nb - 1 : x[t0 - (nb-1) + s]
+    float* red = x_s + (T + nb - 1);
+    const int tid = threadIdx.x;
+    const int h = blockIdx.y, c = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * T;
+    const float* xc = x + (int64_t)c * n * ch + h;
+    float* yc = y + (int64_t)c * n * ch + h;
+    const float* zc = state + ((int64_t)c * ch + h) * (nb - 1);
+    for (int i = tid; i < nb; i += kThreads) b_s[i] = taps[i];
+    for (int s = tid; s < T + nb - 1; s += kThreads) {
+        const int64_t i = t0 - (nb - 1) + s;
+        x_s[s] = (i >= 0 && i < n) ? xc[i * ch] : 0.f;
+    }
+    __syncthreads();
+    float local = 0.f;
+    for (int o = tid; o < T; o += kThreads) {
+        const int64_t i = t0 + o;
+        if (i >= n) break;
+        float acc = 0.f;
+        const int base = o + nb - 1;
+        for (int j = 0; j < nb; ++j) acc = fmaf(b_s[j], x_s[base - j], acc);
+        if (i < nb - 1) acc += zc[i];   // lfilter's initial conditions
+        yc[i * ch] = acc;
+        local += acc;
+    }
+    if (partial != nullptr) {
+        const float t = block_sum(local, red);
+        if (tid == 0) partial[((int64_t)c * ch + h) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_fir_state(const float* __restrict__ x, int64_t n, int ch,
+                                                   const float* __restrict__ taps, int nb,
+                                                   float* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* z_old = smem;  // nb - 1
+    const int h = blockIdx.x % ch, c = blockIdx.x / ch;
+    const float* xc = x + (int64_t)c * n * ch + h;
+    float* zc = state + ((int64_t)c * ch + h) * (nb - 1);
+    for (int s = threadIdx.x; s < nb - 1; s += blockDim.x) z_old[s] = zc[s];
+    __syncthreads();
+    for (int s = threadIdx.x; s < nb - 1; s += blockDim.x) {
+        // zf[s] = sum_i b[s+1+i] x[n-1-i]  (+ what is left of the old state when n < nb-1)
+        float acc = 0.f;
+        const int64_t cnt = (nb - 1 - s) < n ? (nb - 1 - s) : n;
+        for (int64_t i = 0; i < cnt; ++i) acc = fmaf(taps[s + 1 + i], xc[(n - 1 - i) * ch], acc);
+        if (s + n < nb - 1) acc += z_old[s + n];
+        zc[s] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_dc_clip(float* __restrict__ y, int64_t total,
+                                                      const float* __restrict__ partial, int nparts) {
+    __shared__ float mean_s;
+    const int c = blockIdx.y;
+    if (threadIdx.x < 64) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 64) acc += (double)partial[(int64_t)c * nparts + i];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (threadIdx.x == 0) mean_s = (float)(acc / (double)total);
+    }
+    __syncthreads();
+    const float mean = mean_s;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    float v = y[(int64_t)c * total + i] - mean;
+    v = (v < -0.999f) ? -0.999f : ((v > 0.999f) ? 0.999f : v);   // NaN stays NaN like np.clip
+    y[(int64_t)c * total + i] = v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+
+#define RC_LAUNCH_CHECK() RC_HIP(hipGetLastError())
+
+void launch_spectrum_c2c(const float2* X, int64_t x_stride, int64_t n, const int64_t* roll, float2* Y,
+                         int64_t m, int batch, const float* wpos, const float* wneg, float w_merge,
+                         int nyq, int nneg, int nyq_mode, float scale, hipStream_t stream) {
+    if (batch <= 0 || m <= 0) return;
+    hipLaunchKernelGGL(k_spectrum_c2c, grid2(m, kThreads, batch), dim3(kThreads), 0, stream, X, x_stride, n,
+                       roll, Y, m, wpos, wneg, w_merge, nyq, nneg, nyq_mode, scale);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
+                         int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(k_spectrum_r2c, grid2(m / 2 + 1, kThreads, batch), dim3(kThreads), 0, stream, X, n, Y,
+                       m, wr, nyq, nmin, nyq_factor, scale);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_hilbert_mask(const float2* P, float2* Z, int64_t n, int batch, float scale,
+                         hipStream_t stream) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(k_hilbert_mask, grid2(n, kThreads, batch), dim3(kThreads), 0, stream, P, Z, n, scale);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_stereo_unpack(const float2* U, int64_t B, float2* V, int64_t A, int batch, const float* wr,
+                          int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(k_stereo_unpack, grid2(A, kThreads, batch), dim3(kThreads), 0, stream, U, B, V, A, wr,
+                       nyq, nmin, nyq_factor, scale);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipStream_t stream) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(k_discriminator, grid2(n, kThreads, batch), dim3(kThreads), 0, stream, iq, d, n);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_pilot_stage(const float2* iq, const float* x, float* m_out, float* p_out, int64_t n,
+                        int batch, const float* g, int H, float side_tap, hipStream_t stream) {
+    if (batch <= 0) return;
+    const size_t lds = sizeof(float) * ((size_t)(H + 1) + (kPilotTile + 2 * H) + (kPilotTile + 2 * H + 2));
+    hipLaunchKernelGGL(k_pilot_stage, grid2(n, kPilotTile, batch), dim3(kThreads), lds, stream, iq, x, m_out,
+                       p_out, n, g, H, side_tap);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_stereo_mix(const float2* z, const float* m, float2* u, size_t count, hipStream_t stream) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_stereo_mix, dim3((unsigned)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, z, m, u, count);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_pll_phase(const float2* z, size_t count, double mult, int want_imag, float* out,
+                      hipStream_t stream) {
+    if (count == 0) return;
+    int int_power = 0;
+    if (mult >= 1.0 && mult <= 64.0 && mult == (double)(int)mult) int_power = (int)mult;
+    hipLaunchKernelGGL(k_pll_phase, dim3((unsigned)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, z, count, mult, int_power, want_imag, out);
+    RC_LAUNCH_CHECK();
+}
+
+int fir_tiles(int64_t n) { return (int)((n + kFirTile - 1) / kFirTile); }
+
+void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const float* taps, int nb,
+                const float* state, float* partial, hipStream_t stream) {
+    if (batch <= 0 || n <= 0) return;
+    const size_t lds = sizeof(float) * ((size_t)nb + (kFirTile + nb - 1) + 8);
+    hipLaunchKernelGGL(k_fir, dim3((unsigned)fir_tiles(n), (unsigned)ch, (unsigned)batch), dim3(kThreads), lds,
+                       stream, x, y, n, ch, taps, nb, state, partial);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
+                      float* state, hipStream_t stream) {
+    if (batch <= 0 || nb < 2) return;
+    hipLaunchKernelGGL(k_fir_state, dim3((unsigned)(batch * ch)), dim3(128), sizeof(float) * (nb - 1), stream,
+                       x, n, ch, taps, nb, state);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_dc_clip(float* y, int64_t n, int ch, int batch, const float* partial, int tiles,
+                    hipStream_t stream) {
+    if (batch <= 0) return;
+    const int64_t total = n * ch;
+    hipLaunchKernelGGL(k_dc_clip, grid2(total, kThreads, batch), dim3(kThreads), 0, stream, y, total, partial,
+                       tiles * ch);
+    RC_LAUNCH_CHECK();
+}
+
+}  // namespace rcfm

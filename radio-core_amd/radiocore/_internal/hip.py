@@ -1,0 +1,166 @@
+"""ctypes binding of librcfm.so (include/rcfm.h) plus the torch plumbing around it.
+
+This module is the only place that touches the shared library.  There is no
+CPU fallback: if the library is missing or no HIP device is present, loading
+raises, and every class of the package fails with that error.
+
+PyTorch is used for device memory and streams only (torch.empty on the GPU,
+torch.cuda.current_stream); no torch operator computes any part of the path.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "librcfm.so")
+
+RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
+
+_ERR_SIZE, _ERR_INDEX, _ERR_RUNTIME, _ERR_ARG, _ERR_STATE = -1, -2, -3, -4, -5
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+_dbl = ctypes.c_double
+_fp = ctypes.POINTER(ctypes.c_float)
+
+# name -> argtypes; every function returns int except rcfm_last_error.
+SIGNATURES = {
+    "rcfm_version": [],
+    "rcfm_device_count": [ctypes.POINTER(_i)],
+    "rcfm_malloc": [ctypes.POINTER(_vp), _sz],
+    "rcfm_free": [_vp],
+    "rcfm_memcpy_h2d": [_vp, _vp, _sz, _vp],
+    "rcfm_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "rcfm_stream_sync": [_vp],
+    "rcfm_tuner_create": [_i64, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp)],
+    "rcfm_tuner_load": [_vp, _vp, _vp],
+    "rcfm_tuner_run": [_vp, _i, _i, _vp, _vp],
+    "rcfm_tuner_spectrum": [_vp, ctypes.POINTER(_vp)],
+    "rcfm_tuner_destroy": [_vp],
+    "rcfm_demod_create": [_i, _i, _i, _i, _dbl, _i, ctypes.POINTER(_vp)],
+    "rcfm_demod_run": [_vp, _i, _i, _vp, _vp, _vp],
+    "rcfm_demod_reset_state": [_vp, _vp],
+    "rcfm_demod_get_state": [_vp, _fp, _vp],
+    "rcfm_demod_set_state": [_vp, _fp, _vp],
+    "rcfm_demod_get_taps": [_vp, _fp, _fp],
+    "rcfm_demod_destroy": [_vp],
+    "rcfm_pipeline_run": [_vp, _vp, _i, _i, _vp, _vp],
+    "rcfm_resampler_create": [_i, _i, _i, _i, ctypes.POINTER(_vp)],
+    "rcfm_resampler_run": [_vp, _vp, _vp, _vp],
+    "rcfm_resampler_destroy": [_vp],
+    "rcfm_filtfilt": [_i, _i, _fp, _i, _vp, _vp, _vp],
+    "rcfm_lfilter_fir": [_i, _i, _fp, _i, _vp, _vp, _vp, _vp],
+    "rcfm_hilbert": [_i, _i, _vp, _vp, _vp],
+    "rcfm_pll_phase": [_vp, _sz, _dbl, _i, _vp, _vp],
+    "rcfm_discriminator": [_i, _i, _vp, _vp, _vp],
+}
+
+_lib = None
+_torch = None
+
+
+def load_library(path=LIB_PATH):
+    """dlopen librcfm.so and declare every prototype of include/rcfm.h."""
+    if not os.path.exists(path):
+        raise ImportError(
+            "librcfm.so not found at %s -- build it with `make -C radio-core_amd` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    lib.rcfm_last_error.argtypes = []
+    lib.rcfm_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def torch():
+    """torch with a usable HIP device, or a loud failure."""
+    global _torch
+    if _torch is None:
+        import torch as _t
+        if not _t.cuda.is_available():
+            raise RuntimeError("radiocore (MI355X build) needs a HIP device; none is visible "
+                               "and there is no CPU fallback")
+        _torch = _t
+    return _torch
+
+
+def check(status):
+    """Map an rcfm_status to the exception the reference raises at that point."""
+    if status == 0:
+        return
+    msg = lib().rcfm_last_error().decode("utf-8", "replace")
+    if status == _ERR_SIZE:
+        raise ValueError(msg or "input_sig size and input_size mismatch")
+    if status == _ERR_INDEX:
+        raise IndexError(msg or "list index out of range")
+    if status == _ERR_ARG:
+        raise ValueError(msg)
+    raise RuntimeError("librcfm: %s (status %d)" % (msg, status))
+
+
+def stream():
+    return _vp(torch().cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return _vp(t.data_ptr())
+
+
+def to_device(x, dtype=None):
+    """Host array / sequence / tensor -> contiguous device tensor (H2D if needed)."""
+    t = torch()
+    if isinstance(x, t.Tensor):
+        out = x
+    else:
+        a = np.asarray(x)
+        if a.dtype == np.float64:
+            a = a.astype(np.float32)
+        elif a.dtype == np.complex128:
+            a = a.astype(np.complex64)
+        out = t.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None and out.dtype != dtype:
+        out = out.to(dtype)
+    return out.to("cuda", non_blocking=False).contiguous()
+
+
+def to_host(x):
+    return x.cpu().numpy()
+
+
+def empty(shape, dtype):
+    return torch().empty(shape, dtype=dtype, device="cuda")
+
+
+def float_array(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_fp)
+
+
+class Handle:
+    """Owns one opaque librcfm handle and destroys it with the given function."""
+
+    def __init__(self, value, destroy):
+        self.value = value
+        self._destroy = destroy
+
+    def __del__(self):
+        try:
+            if self.value:
+                self._destroy(self.value)
+                self.value = None
+        except Exception:
+            pass

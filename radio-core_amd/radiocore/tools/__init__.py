@@ -1,0 +1,3 @@
+"""Imports all modules from radiocore.tools."""
+
+from radiocore.tools.tuner import *

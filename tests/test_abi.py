@@ -1,0 +1,91 @@
+"""CPU: librcfm.so loads and exports exactly what include/rcfm.h declares.
+
+No compute calls (this container has no GPU); the parity tests proper are the
+`-m gpu` ones, which go through this same ABI.
+"""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "rcfm.h")
+LIB = os.path.join(ROOT, "radio-core_amd", "radiocore", "_lib", "librcfm.so")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rcfm_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("rcfm_tuner_create", "rcfm_tuner_load", "rcfm_tuner_run", "rcfm_demod_create",
+                 "rcfm_demod_run", "rcfm_pipeline_run", "rcfm_resampler_run", "rcfm_filtfilt",
+                 "rcfm_lfilter_fir", "rcfm_hilbert", "rcfm_pll_phase", "rcfm_discriminator"):
+        assert must in names
+    assert len(names) >= 28
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header():
+    from radiocore._internal import hip
+    bound = set(hip.SIGNATURES) | {"rcfm_last_error"}
+    assert bound == set(declared_functions())
+
+
+def test_version_and_error_string(lib):
+    lib.rcfm_version.restype = ctypes.c_int
+    assert lib.rcfm_version() == 100
+    lib.rcfm_last_error.restype = ctypes.c_char_p
+    assert isinstance(lib.rcfm_last_error(), bytes)
+
+
+def test_argument_errors_need_no_device(lib):
+    """NULL / bad-size arguments are rejected before any HIP call."""
+    lib.rcfm_tuner_create.restype = ctypes.c_int
+    assert lib.rcfm_tuner_create(ctypes.c_int64(0), 0, None, None, None) == -4
+    out = ctypes.c_void_p()
+    assert lib.rcfm_demod_create(7, 1, 100, 10, ctypes.c_double(75e-6), 0, ctypes.byref(out)) == -4
+    lib.rcfm_last_error.restype = ctypes.c_char_p
+    assert b"kind" in lib.rcfm_last_error()
+
+
+def test_package_fails_loudly_without_a_device():
+    """The product has no CPU fallback: constructing a class without a HIP device raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    import radiocore
+    assert radiocore.HasCuda() is False
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        radiocore.MFM(240000, 48000)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        radiocore.Tuner()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "radio-core_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(d, f)).read()
+                assert "radiocore_oracle" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert not re.search(r"#include\s+\"[^\"]*oracle", text), f
