@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Throughput of the Tuner -> WBFM hot path on MI355X (BASELINE.json config 4).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one pass of the hot path over one 1-second wideband buffer that is
+already resident in HBM: Tuner.load (FFT of N = 240 000 000 complex64 samples)
+then, for this rank's share of the 1024 channels, Tuner.run + WBFM.run
+(240 kHz -> 48 kHz stereo), then (N > 1) the RCCL gather of the audio to rank 0.
+Channels shard across ranks; the wideband FFT cannot shard by channel and is
+replicated, so total work is fixed as ranks grow: "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (dominant stage, algorithmic bytes per launch / HIP-event time per
+launch, against 8 TB/s) and, at N = 1, `cpu_baseline` (the numpy oracle timed on
+this box's host cores on a bounded sample: one load + a few channels).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "radio-core_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table (spec); 6.29e12 measured copy ceiling
+
+CONFIGS = {
+    # name: (N wideband samples, channels, B, A, raster Hz, demod)
+    "cfg4": (240_000_000, 1024, 240_000, 48_000, 200_000, "WBFM"),
+    "cfg3": (10_000_000, 64, 240_000, 48_000, 150_000, "MFM"),
+    "cfg5": (100_000_000, 8192, 12_500, 8_000, 12_000, "FM"),
+    "small": (2_400_000, 16, 240_000, 48_000, 140_000, "WBFM"),
+}
+
+# Algorithmic bytes of each stage per unit:
+# per wideband sample for the tuner FFT, per channel for everything else.
+def stage_bytes(name, N, B, A, kind):
+    ch = 2 if kind == "WBFM" else 1
+    table = {
+        "tuner_fft_N": 16 * N,                 # read 8N, write 8N (once per buffer)
+        "tuner_gather": 16 * B,                # read 8B bins, write 8B
+        "tuner_ifft_B": 16 * B,
+        "discriminator": 12 * B,               # read 8B, write 4B
+        "pilot_stage": 16 * B,                 # read 8B, write m 4B + p 4B
+        "rfft_B": 8 * B,                       # read 4B, write 4B (half spectrum)
+        "hilbert_mask": 12 * B,                # read 4B, write 8B
+        "ifft_B": 16 * B,
+        "stereo_mix": 20 * B,                  # read z 8B + m 4B, write 8B
+        "fft_B": 16 * B,
+        "audio_spectrum": 8 * A * ch + 8 * A * ch / 2,
+        "ifft_A": 16 * A if kind == "WBFM" else 8 * A,
+        "deemphasis": 8 * A * ch,
+        "deemph_state": 0,
+        "dc_clip": 8 * A * ch,
+    }
+    return float(table[name])
+
+
+def path_bytes(N, C, B, A, kind):
+    """Algorithmic bytes of the whole path per buffer (SURVEY.md 8d totals)."""
+    per_ch = {"FM": 8 * B + 12 * A, "MFM": 8 * B + 20 * A, "WBFM": 48 * B + 40 * A}[kind]
+    return 16.0 * N + C * (16.0 * B + per_ch)
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def synth_wideband_on_device(N, C, B, raster, kind, lib, hip):
+    """Seeded synthetic wideband buffer built on the GPU (input generation is not the
+    product: torch ops are used freely here).  Stations sit on the channel centres;
+    each is an FM signal whose modulation is integer-Hz tones (+ 19 kHz pilot and a
+    38 kHz DSB L-R component for WBFM), so it is periodic in the 1-second buffer."""
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    centres = [float(int(100e6 + (i - (C - 1) / 2.0) * raster)) for i in range(C)]
+    lower = min(centres) - B / 2
+    higher = max(centres) + B / 2
+    f_in = (lower + higher) / 2
+    Xw = torch.zeros(N, dtype=torch.complex64, device=dev)
+    t = torch.arange(B, device=dev, dtype=torch.float64) / B
+    kk = torch.fft.fftfreq(B, 1.0 / B, device=dev).round().to(torch.int64)
+    dev_hz = 75e3 * B / 240000.0 if kind != "FM" else 0.2 * B
+    gain = 0.5 / np.sqrt(max(C * B / N, 1.0))
+    step = 32
+    for c0 in range(0, C, step):
+        idx = torch.arange(c0, min(c0 + step, C))
+        k = (idx % 89).to(torch.float64).to(dev)[:, None]
+        ph = (torch.rand((len(idx), 6), generator=g, dtype=torch.float64) * 2 * np.pi).to(dev)
+        two_pi_t = 2 * np.pi * t[None, :]
+        L = 0.3 * (torch.sin((300 + 37 * k) * two_pi_t + ph[:, 0:1]) + torch.sin((1000 + 11 * k) * two_pi_t + ph[:, 1:2])
+                   + torch.sin((5000 + 3 * k) * two_pi_t + ph[:, 2:3]))
+        R = 0.35 * (torch.sin((440 + 29 * k) * two_pi_t + ph[:, 3:4]) + torch.sin((2500 + 7 * k) * two_pi_t + ph[:, 4:5]))
+        if kind == "WBFM":
+            mpx = 0.3 * (L + R) + 0.1 * torch.sin(19000 * two_pi_t) + 0.3 * (L - R) * torch.sin(38000 * two_pi_t)
+        else:
+            mpx = 0.5 * L
+        phase = 2 * np.pi * dev_hz * torch.cumsum(mpx, dim=1) / B
+        s = torch.polar(torch.ones_like(phase), phase).to(torch.complex64)
+        S = torch.fft.fft(s, dim=1) * (gain * N / B)
+        for j, i in enumerate(idx.tolist()):
+            off = int(centres[i] - f_in)
+            Xw.index_add_(0, (kk + off) % N, S[j])
+        del L, R, mpx, phase, s, S
+    # x = IFFT_N(Xw) = conj(FFT_N(conj(Xw))) / N, using the library's own wideband FFT
+    roll = (ctypes.c_int64 * 1)(0)
+    bw = (ctypes.c_int32 * 1)(min(B, N))
+    h = ctypes.c_void_p()
+    hip.check(lib.rcfm_tuner_create(N, 1, roll, bw, ctypes.byref(h)))
+    Xw = torch.conj_physical(Xw)
+    hip.check(lib.rcfm_tuner_load(h, hip.ptr(Xw), hip.stream()))
+    spec = ctypes.c_void_p()
+    hip.check(lib.rcfm_tuner_spectrum(h, ctypes.byref(spec)))
+    x = torch.empty(N, dtype=torch.complex64, device=dev)
+    hip.check(lib.rcfm_memcpy_d2d(hip.ptr(x), spec, N * 8, hip.stream()))
+    torch.cuda.synchronize()
+    hip.check(lib.rcfm_tuner_destroy(h))
+    x = torch.conj_physical(x) / N
+    noise = torch.randn(N, 2, generator=torch.Generator(device=dev).manual_seed(7), device=dev) * 0.003
+    x += torch.view_as_complex(noise)
+    del Xw, noise
+    torch.cuda.synchronize()
+    return x.contiguous(), centres, f_in
+
+
+def read_profile(lib):
+    n = lib.rcfm_profile_stage_count()
+    out = {}
+    for st in range(n):
+        ms = ctypes.c_double()
+        cnt = ctypes.c_int64()
+        lib.rcfm_profile_read(st, ctypes.byref(ms), ctypes.byref(cnt))
+        out[lib.rcfm_profile_stage_name(st).decode()] = (st, ms.value, cnt.value)
+    return out
+
+
+def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan):
+    """The oracle (a numpy port of the reference's CPU path), one thread, on a bounded
+    sample: one Tuner.load of the full buffer + `nchan` channels of Tuner.run + demod,
+    extrapolated as t_load + C * mean(t_channel).  Test infrastructure used as a
+    reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import radiocore_oracle as oracle
+    tuner = oracle.Tuner()
+    for f in centres:
+        tuner.add_channel(f, B, None)
+    tuner.request_bandwidth(float(N))
+    t0 = time.perf_counter()
+    tuner.load(x_host)
+    t_load = time.perf_counter() - t0
+    demod = getattr(oracle, kind)(B, A)
+    t_ch = []
+    for i in np.linspace(0, C - 1, nchan).astype(int):
+        t0 = time.perf_counter()
+        iq = tuner.run(int(i))            # reference-faithful O(N) roll + window
+        demod.run(iq)
+        t_ch.append(time.perf_counter() - t0)
+    t_total = t_load + C * float(np.mean(t_ch))
+    return {
+        "value": N / t_total / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "sample": "oracle Tuner.load on the full %d-sample buffer (%.1f s) + %d of %d channels of "
+                  "Tuner.run+%s.run (mean %.2f s each), extrapolated t_load + C*t_channel = %.0f s per buffer; "
+                  "host has %d logical cores" % (N, t_load, nchan, C, kind, float(np.mean(t_ch)), t_total,
+                                                 os.cpu_count()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--chunk", type=int, default=0, help="channels per pass (0 = library default)")
+    ap.add_argument("--cpu-channels", type=int, default=3, help="channels in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr")
+    args = ap.parse_args()
+
+    rank, world, local = dist_env()
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    from radiocore._internal import hip
+    lib = hip.lib()
+    hip.torch()
+
+    N, C, B, A, raster, kind = CONFIGS[args.config]
+    ch = 2 if kind == "WBFM" else 1
+    x, centres, f_in = synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
+
+    # this rank's contiguous share of the channels
+    lo = rank * C // world
+    hi = (rank + 1) * C // world
+    mine = hi - lo
+    rolls = [int(f_in - f) for f in centres]
+    roll_a = (ctypes.c_int64 * C)(*rolls)
+    bw_a = (ctypes.c_int32 * C)(*([B] * C))
+    tuner = ctypes.c_void_p()
+    hip.check(lib.rcfm_tuner_create(N, C, roll_a, bw_a, ctypes.byref(tuner)))
+    demod = ctypes.c_void_p()
+    kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
+    hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
+    audio = torch.empty((mine, A, ch), dtype=torch.float32, device="cuda")
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty((((r + 1) * C // world) - (r * C // world), A, ch), dtype=torch.float32,
+                                device="cuda") for r in range(world)] if rank == 0 else None
+
+    def step():
+        s = hip.stream()
+        hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
+        # pipeline_run addresses channels of tuner and demod by the same index
+        hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), s))
+        if world > 1:
+            dist.gather(audio, gathered, dst=0)          # RCCL over xGMI: the only collective on the path
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # pass 1 (untimed): every stage bracketed, to find the dominant one
+    lib.rcfm_profile_reset()
+    lib.rcfm_profile_enable(ctypes.c_uint64((1 << lib.rcfm_profile_stage_count()) - 1))
+    step()
+    torch.cuda.synchronize()
+    prof_all = read_profile(lib)
+    lib.rcfm_profile_enable(ctypes.c_uint64(0))
+    dominant = max(prof_all, key=lambda k: prof_all[k][1])
+    if args.profile_all and rank == 0:
+        tot = sum(v[1] for v in prof_all.values())
+        for k, (st, ms, cnt) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
+            per = ms / max(cnt, 1)
+            by = stage_bytes(k, N, B, A, kind) * (1 if k == "tuner_fft_N" else mine / max(cnt, 1))
+            print("%-16s %9.3f ms  %5d launches  %8.1f us each  %6.2f TB/s algorithmic  %4.1f%%" %
+                  (k, ms, cnt, per * 1e3, by / (per * 1e-3) / 1e12 if per else 0, 100 * ms / tot), file=sys.stderr)
+            del units
+
+    # timed region: exactly K steps, barrier + synchronize on both sides; only the
+    # dominant stage keeps its event pairs (on the stream the kernels run on)
+    lib.rcfm_profile_reset()
+    lib.rcfm_profile_enable(ctypes.c_uint64(1 << prof_all[dominant][0]))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom = read_profile(lib)[dominant]
+    lib.rcfm_profile_enable(ctypes.c_uint64(0))
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N * args.steps / elapsed / 1e6
+    launches_per_step = dom[2] / args.steps
+    per_launch_s = dom[1] * 1e-3 / max(dom[2], 1)
+    units = 1.0 if dominant == "tuner_fft_N" else mine / max(launches_per_step, 1)
+    alg_bytes = stage_bytes(dominant, N, B, A, kind) * units
+    achieved = alg_bytes / per_launch_s if per_launch_s else 0.0
+    total_alg = 16.0 * N + mine * (path_bytes(N, C, B, A, kind) - 16.0 * N) / C
+
+    result = {
+        "metric": "IQ Msamples/s through Tuner+%s at %d channels" % (kind, C),
+        "value": round(value, 2),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %d-channel Tuner at %d MSPS complex64 -> %d x %s (%d -> %d Hz), 1-second buffers, "
+                        "input resident in HBM" % (args.config, C, N // 1_000_000, C, kind, B, A),
+            "channels": C, "channels_per_gpu": mine, "wideband_samples": N, "channel_samples": B,
+            "audio_samples": A, "parallelism": "channels sharded x%d, wideband FFT replicated, RCCL gather" % world
+            if world > 1 else "single GPU",
+        },
+        "path_hbm_frac": round(total_alg / (ms_per_step * 1e-3) / HBM_PEAK, 4),
+        "path_algorithmic_GB": round(total_alg / 1e9, 3),
+        "roofline": {
+            "bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+            "launch_us": round(per_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "share_of_step": round(dom[1] / args.steps / ms_per_step, 3),
+        },
+    }
+
+    if rank == 0 and world == 1 and args.cpu_channels > 0:
+        x_host = x.cpu().numpy()
+        result["cpu_baseline"] = cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, args.cpu_channels)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    hip.check(lib.rcfm_demod_destroy(demod))
+    hip.check(lib.rcfm_tuner_destroy(tuner))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,7 @@ int rcfm_malloc(void** dptr, size_t bytes);
 int rcfm_free(void* dptr);
 int rcfm_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
 int rcfm_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
+int rcfm_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 int rcfm_stream_sync(void* stream);
 
 /* ---- Tuner (radiocore/tools/tuner.py) ------------------------------------ */
@@ -141,6 +142,19 @@ int rcfm_pll_phase(const void* z, size_t count, double mult, int want_imag, void
                    void* stream);
 /* FM discriminator, fm.py:60-65: iq [C][n] complex64 -> d [C][n] float32 (d[0] = 0). */
 int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream);
+
+/* ---- measurement ------------------------------------------------------------ */
+
+/* Per-stage timing with HIP events recorded on the stage's own stream (the reference
+ * has only timeit around whole calls, tests/benchmark.py:22-24).  A stage is one
+ * kernel launch or one FFT execute.  enable(mask): bit i switches stage i on;
+ * read(): waits for the recorded events and returns the accumulated milliseconds
+ * and the number of bracketed launches since the last reset. */
+int rcfm_profile_stage_count(void);
+const char* rcfm_profile_stage_name(int stage);
+int rcfm_profile_enable(uint64_t stage_mask);
+int rcfm_profile_reset(void);
+int rcfm_profile_read(int stage, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,91 @@ struct PlanCache {
     }
 };
 
+// ---- per-stage HIP-event timing (rcfm_profile_*) ------------------------------
+// bench.py reads these to price the dominant stage against the HBM roofline.
+enum Stage : int {
+    ST_TUNER_FFT = 0,   // T1  wideband forward FFT
+    ST_TUNER_GATHER,    // T2a bin gather + weight
+    ST_TUNER_IFFT,      // T2b per-channel inverse FFT
+    ST_DISC,            // F1  discriminator (FM/MFM)
+    ST_PILOT,           // W1  discriminator + 3-tap + pilot FIR
+    ST_FFT_REAL_B,      // r2c of length B (pilot or discriminator)
+    ST_HILBERT_MASK,    // W2b
+    ST_IFFT_B,          // W2c analytic signal
+    ST_STEREO_MIX,      // W3a
+    ST_FFT_B,           // W3b packed L/R forward FFT
+    ST_AUDIO_SPECTRUM,  // W4a unpack / real spectrum resample
+    ST_IFFT_A,          // W4b inverse FFT of length A (c2c packed or c2r)
+    ST_DEEMPH,          // W5a FIR51 + partial sums
+    ST_DEEMPH_STATE,    // W5b
+    ST_DC_CLIP,         // W5c
+    ST_COUNT
+};
+
+const char* const kStageNames[ST_COUNT] = {
+    "tuner_fft_N",   "tuner_gather",  "tuner_ifft_B", "discriminator", "pilot_stage",
+    "rfft_B",        "hilbert_mask",  "ifft_B",       "stereo_mix",    "fft_B",
+    "audio_spectrum", "ifft_A",       "deemphasis",   "deemph_state",  "dc_clip"};
+
+struct Profiler {
+    uint64_t mask = 0;
+    struct Pair {
+        hipEvent_t a, b;
+    };
+    std::vector<Pair> pending[ST_COUNT];
+    std::vector<Pair> pool;
+    double total_ms[ST_COUNT] = {};
+    int64_t count[ST_COUNT] = {};
+
+    bool on(int st) const { return (mask >> st) & 1u; }
+    Pair take() {
+        if (!pool.empty()) {
+            Pair p = pool.back();
+            pool.pop_back();
+            return p;
+        }
+        Pair p;
+        RC_HIP(hipEventCreate(&p.a));
+        RC_HIP(hipEventCreate(&p.b));
+        return p;
+    }
+    void collect() {
+        for (int st = 0; st < ST_COUNT; ++st) {
+            for (auto& p : pending[st]) {
+                RC_HIP(hipEventSynchronize(p.b));
+                float ms = 0.f;
+                RC_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+                total_ms[st] += ms;
+                count[st] += 1;
+                pool.push_back(p);
+            }
+            pending[st].clear();
+        }
+    }
+};
+
+Profiler g_prof;
+
+// Brackets one stage (one kernel, or one rocFFT execute) with events on its stream.
+struct StageTimer {
+    int st;
+    hipStream_t s;
+    Profiler::Pair p{};
+    bool live;
+    StageTimer(int stage, hipStream_t stream) : st(stage), s(stream), live(g_prof.on(stage)) {
+        if (live) {
+            p = g_prof.take();
+            RC_HIP(hipEventRecord(p.a, s));
+        }
+    }
+    ~StageTimer() {
+        if (live) {
+            (void)hipEventRecord(p.b, s);
+            g_prof.pending[st].push_back(p);
+        }
+    }
+};
+
 }  // namespace
 }  // namespace rcfm
 
@@ -186,10 +271,16 @@ struct rcfm_tuner_s {
         FftPlan& inv = bd.inverse.get(FftKind::C2C_INVERSE, (size_t)B, count, true, need);
         work.reserve(need);
         const ResampleGeom& g = bd.geom;
-        launch_spectrum_c2c(X.as<float2>(), 0, n, roll_dev.as<int64_t>() + first, out, B, count,
-                            g.wpos.as<float>(), g.wneg.as<float>(), g.w_merge, g.nyq, g.nneg, g.nyq_mode,
-                            g.scale, s);
-        inv.exec(out, out, work.get(), s);
+        {
+            StageTimer tm(ST_TUNER_GATHER, s);
+            launch_spectrum_c2c(X.as<float2>(), 0, n, roll_dev.as<int64_t>() + first, out, B, count,
+                                g.wpos.as<float>(), g.wneg.as<float>(), g.w_merge, g.nyq, g.nneg, g.nyq_mode,
+                                g.scale, s);
+        }
+        {
+            StageTimer tm(ST_TUNER_IFFT, s);
+            inv.exec(out, out, work.get(), s);
+        }
     }
 };
 
@@ -246,23 +337,56 @@ struct rcfm_demod_s {
             float2* Z = buf_Z.as<float2>();
             float2* V = buf_V.as<float2>();
             // wbfm.py:77-80  FM(B->B) and the pilot band-pass
-            launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
+            {
+                StageTimer tm(ST_PILOT, s);
+                launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
+            }
             // wbfm.py:80 / pll.py:34  analytic signal of the pilot
-            f1.exec(p, P, work.get(), s);
-            launch_hilbert_mask(P, Z, B, cnt, 1.0f / (float)B, s);
-            f2.exec(Z, Z, work.get(), s);
+            {
+                StageTimer tm(ST_FFT_REAL_B, s);
+                f1.exec(p, P, work.get(), s);
+            }
+            {
+                StageTimer tm(ST_HILBERT_MASK, s);
+                launch_hilbert_mask(P, Z, B, cnt, 1.0f / (float)B, s);
+            }
+            {
+                StageTimer tm(ST_IFFT_B, s);
+                f2.exec(Z, Z, work.get(), s);
+            }
             // wbfm.py:83,86-87  38 kHz carrier, L-R, stereo matrix; both legs packed in one complex signal
-            launch_stereo_mix(Z, m, Z, (size_t)cnt * B, s);
-            f3.exec(Z, Z, work.get(), s);
-            launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin, geom.nyq_factor,
-                                 geom.scale, s);
-            f4.exec(V, V, work.get(), s);   // -> [cnt][A][2] float32, L/R interleaved
+            {
+                StageTimer tm(ST_STEREO_MIX, s);
+                launch_stereo_mix(Z, m, Z, (size_t)cnt * B, s);
+            }
+            {
+                StageTimer tm(ST_FFT_B, s);
+                f3.exec(Z, Z, work.get(), s);
+            }
+            {
+                StageTimer tm(ST_AUDIO_SPECTRUM, s);
+                launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
+                                     geom.nyq_factor, geom.scale, s);
+            }
+            {
+                StageTimer tm(ST_IFFT_A, s);
+                f4.exec(V, V, work.get(), s);   // -> [cnt][A][2] float32, L/R interleaved
+            }
             // wbfm.py:90-100  de-emphasis (separate L/R state), joint DC removal, clip
             float* st = state.as<float>() + (size_t)first * ch * 50;
-            launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
-                       partial.as<float>(), s);
-            launch_fir_state(reinterpret_cast<float*>(V), A, 2, cnt, taps.as<float>(), 51, st, s);
-            launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles, s);
+            {
+                StageTimer tm(ST_DEEMPH, s);
+                launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
+                           partial.as<float>(), s);
+            }
+            {
+                StageTimer tm(ST_DEEMPH_STATE, s);
+                launch_fir_state(reinterpret_cast<float*>(V), A, 2, cnt, taps.as<float>(), 51, st, s);
+            }
+            {
+                StageTimer tm(ST_DC_CLIP, s);
+                launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles, s);
+            }
             return;
         }
         FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);
@@ -272,20 +396,43 @@ struct rcfm_demod_s {
         float2* D = buf_P.as<float2>();
         float2* Y = buf_V.as<float2>();
         // fm.py:60-66  discriminator, then Decimate(B -> A)
-        launch_discriminator(iq, d, B, cnt, s);
-        f1.exec(d, D, work.get(), s);
-        launch_spectrum_r2c(D, B, Y, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin, geom.nyq_factor, geom.scale, s);
+        {
+            StageTimer tm(ST_DISC, s);
+            launch_discriminator(iq, d, B, cnt, s);
+        }
+        {
+            StageTimer tm(ST_FFT_REAL_B, s);
+            f1.exec(d, D, work.get(), s);
+        }
+        {
+            StageTimer tm(ST_AUDIO_SPECTRUM, s);
+            launch_spectrum_r2c(D, B, Y, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin, geom.nyq_factor,
+                                geom.scale, s);
+        }
         if (kind == RCFM_FM) {
+            StageTimer tm(ST_IFFT_A, s);
             f2.exec(Y, audio, work.get(), s);
             return;
         }
         float* v = buf_v.as<float>();
-        f2.exec(Y, v, work.get(), s);
+        {
+            StageTimer tm(ST_IFFT_A, s);
+            f2.exec(Y, v, work.get(), s);
+        }
         // mfm.py:63-65
         float* st = state.as<float>() + (size_t)first * 50;
-        launch_fir(v, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
-        launch_fir_state(v, A, 1, cnt, taps.as<float>(), 51, st, s);
-        launch_dc_clip(audio, A, 1, cnt, partial.as<float>(), tiles, s);
+        {
+            StageTimer tm(ST_DEEMPH, s);
+            launch_fir(v, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
+        }
+        {
+            StageTimer tm(ST_DEEMPH_STATE, s);
+            launch_fir_state(v, A, 1, cnt, taps.as<float>(), 51, st, s);
+        }
+        {
+            StageTimer tm(ST_DC_CLIP, s);
+            launch_dc_clip(audio, A, 1, cnt, partial.as<float>(), tiles, s);
+        }
     }
 };
 
@@ -337,6 +484,10 @@ int rcfm_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream)
     return guarded([&] { RC_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream))); });
 }
 
+int rcfm_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    return guarded([&] { RC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream))); });
+}
+
 int rcfm_stream_sync(void* stream) {
     return guarded([&] { RC_HIP(hipStreamSynchronize(as_stream(stream))); });
 }
@@ -373,7 +524,10 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
     return guarded([&] {
         RC_REQUIRE(t && x, RCFM_ERR_ARG, "NULL argument");
         t->work.reserve(t->forward->work_bytes());
-        t->forward->exec(const_cast<void*>(x), t->X.get(), t->work.get(), as_stream(stream));
+        {
+            StageTimer tm(ST_TUNER_FFT, as_stream(stream));
+            t->forward->exec(const_cast<void*>(x), t->X.get(), t->work.get(), as_stream(stream));
+        }
         t->loaded = true;
     });
 }
@@ -623,6 +777,40 @@ int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream) {
     return guarded([&] {
         RC_REQUIRE(iq && d, RCFM_ERR_ARG, "NULL argument");
         launch_discriminator(static_cast<const float2*>(iq), static_cast<float*>(d), n, C, as_stream(stream));
+    });
+}
+
+// ---- profiling ------------------------------------------------------------------
+
+int rcfm_profile_stage_count(void) { return ST_COUNT; }
+
+const char* rcfm_profile_stage_name(int stage) {
+    return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
+}
+
+int rcfm_profile_enable(uint64_t stage_mask) {
+    return guarded([&] {
+        g_prof.collect();
+        g_prof.mask = stage_mask;
+    });
+}
+
+int rcfm_profile_reset(void) {
+    return guarded([&] {
+        g_prof.collect();
+        for (int i = 0; i < ST_COUNT; ++i) {
+            g_prof.total_ms[i] = 0.0;
+            g_prof.count[i] = 0;
+        }
+    });
+}
+
+int rcfm_profile_read(int stage, double* total_ms, int64_t* launches) {
+    return guarded([&] {
+        RC_REQUIRE(stage >= 0 && stage < ST_COUNT && total_ms && launches, RCFM_ERR_ARG, "bad stage");
+        g_prof.collect();
+        *total_ms = g_prof.total_ms[stage];
+        *launches = g_prof.count[stage];
     });
 }
 

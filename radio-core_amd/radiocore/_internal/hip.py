@@ -35,6 +35,7 @@ SIGNATURES = {
     "rcfm_free": [_vp],
     "rcfm_memcpy_h2d": [_vp, _vp, _sz, _vp],
     "rcfm_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "rcfm_memcpy_d2d": [_vp, _vp, _sz, _vp],
     "rcfm_stream_sync": [_vp],
     "rcfm_tuner_create": [_i64, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp)],
     "rcfm_tuner_load": [_vp, _vp, _vp],
@@ -57,6 +58,10 @@ SIGNATURES = {
     "rcfm_hilbert": [_i, _i, _vp, _vp, _vp],
     "rcfm_pll_phase": [_vp, _sz, _dbl, _i, _vp, _vp],
     "rcfm_discriminator": [_i, _i, _vp, _vp, _vp],
+    "rcfm_profile_stage_count": [],
+    "rcfm_profile_enable": [ctypes.c_uint64],
+    "rcfm_profile_reset": [],
+    "rcfm_profile_read": [_i, ctypes.POINTER(_dbl), ctypes.POINTER(_i64)],
 }
 
 _lib = None
@@ -74,8 +79,10 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _i
+    for name in ("rcfm_last_error", "rcfm_profile_stage_name"):
+        getattr(lib, name).restype = ctypes.c_char_p
     lib.rcfm_last_error.argtypes = []
-    lib.rcfm_last_error.restype = ctypes.c_char_p
+    lib.rcfm_profile_stage_name.argtypes = [_i]
     return lib
 
 

@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_binding_table_matches_header():
     from radiocore._internal import hip
-    bound = set(hip.SIGNATURES) | {"rcfm_last_error"}
+    bound = set(hip.SIGNATURES) | {"rcfm_last_error", "rcfm_profile_stage_name"}
     assert bound == set(declared_functions())
 
 
