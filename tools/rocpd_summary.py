@@ -14,7 +14,7 @@ def main(path, limit=40, only=None):
     for name, calls, total, avg, pct in rows[:limit]:
         if only and only not in name:
             continue
-        short = name.split("(")[0].replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if len(short) > 110:
             short = short[:107] + "..."
         print("| `%s` | %d | %.3f | %.2f | %.2f |" % (short, calls, total / 1e3, avg, pct))
