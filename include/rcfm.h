@@ -143,6 +143,32 @@ int rcfm_pll_phase(const void* z, size_t count, double mult, int want_imag, void
 /* FM discriminator, fm.py:60-65: iq [C][n] complex64 -> d [C][n] float32 (d[0] = 0). */
 int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream);
 
+/* ---- FFT engine (the hand-written replacement of cupy.fft / scipy.fft calls) -- */
+
+/* Describes how librcfm runs a length-n complex FFT: fills a POD `rcfm_fft_plan`
+ * (layout below) and returns 0, or RCFM_ERR_ARG when n is outside the engine
+ * (radices other than 2/3/5, n < 256, more than 4 passes): such lengths use rocFFT. */
+typedef struct rcfm_fft_pass {
+    int32_t L, nstages, radix[8];
+    int64_t n_o1, n_o2, n_inner;
+    int64_t in_o1, in_o2, in_i, in_l;
+    int64_t out_o1, out_o2, out_i, out_k;
+    int64_t tw_o1, tw_o2, tw_i;
+    int32_t has_twiddle, load_along_l;
+} rcfm_fft_pass;
+typedef struct rcfm_fft_plan {
+    int64_t n;
+    int32_t npass, fine_bits;
+    rcfm_fft_pass pass[4];
+} rcfm_fft_plan;
+int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);
+/* Unnormalised forward (inverse = 0) or conjugate (inverse = 1) transform of `batch`
+ * contiguous length-n complex64 signals; in == out allowed.  (scipy.fft.fft / ifft*n) */
+int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);
+/* The same transform through rocFFT (any n): the A/B partner of rcfm_fft_c2c in
+ * tools/bench_fft.py and the fallback for lengths the engine refuses. */
+int rcfm_fft_c2c_rocfft(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);
+
 /* ---- measurement ------------------------------------------------------------ */
 
 /* Per-stage timing with HIP events recorded on the stage's own stream (the reference

@@ -7,9 +7,11 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
+#include "fft_engine.h"
 #include "fft_plan.h"
 #include "kernels.h"
 
@@ -777,6 +779,53 @@ int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream) {
     return guarded([&] {
         RC_REQUIRE(iq && d, RCFM_ERR_ARG, "NULL argument");
         launch_discriminator(static_cast<const float2*>(iq), static_cast<float*>(d), n, C, as_stream(stream));
+    });
+}
+
+// ---- FFT engine --------------------------------------------------------------------
+
+static_assert(sizeof(rcfm_fft_pass) == sizeof(FftPass), "ABI mirror of FftPass out of date");
+static_assert(sizeof(rcfm_fft_plan) == sizeof(FftPlanDesc), "ABI mirror of FftPlanDesc out of date");
+
+int rcfm_fft_describe(int64_t n, int max_l, rcfm_fft_plan* plan) {
+    return guarded([&] {
+        RC_REQUIRE(plan != nullptr, RCFM_ERR_ARG, "plan is NULL");
+        FftPlanDesc d;
+        RC_REQUIRE(fft_plan_describe(n, &d, max_l), RCFM_ERR_ARG, "length not supported by the FFT engine");
+        std::memcpy(plan, &d, sizeof(d));
+    });
+}
+
+int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(in && out && batch >= 1, RCFM_ERR_ARG, "bad argument");
+        static std::mutex mu;
+        static std::map<int64_t, std::unique_ptr<FftEngine>> engines;
+        static DeviceBuffer tmp;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = engines.find(n);
+        if (it == engines.end()) it = engines.emplace(n, std::make_unique<FftEngine>(n)).first;
+        tmp.reserve((size_t)batch * n * sizeof(float2));
+        it->second->c2c(static_cast<const float2*>(in), static_cast<float2*>(out), tmp.as<float2>(), batch,
+                        inverse != 0, 1.0f, as_stream(stream));
+    });
+}
+
+int rcfm_fft_c2c_rocfft(int64_t n, int batch, int inverse, const void* in, void* out, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(in && out && batch >= 1 && n >= 1, RCFM_ERR_ARG, "bad argument");
+        static std::mutex mu;
+        static std::map<std::tuple<int64_t, int, int, int>, std::unique_ptr<FftPlan>> plans;
+        static DeviceBuffer work;
+        std::lock_guard<std::mutex> lock(mu);
+        const bool in_place = (in == out);
+        auto key = std::make_tuple(n, batch, inverse ? 1 : 0, in_place ? 1 : 0);
+        auto it = plans.find(key);
+        if (it == plans.end())
+            it = plans.emplace(key, std::make_unique<FftPlan>(inverse ? FftKind::C2C_INVERSE : FftKind::C2C_FORWARD,
+                                                               (size_t)n, (size_t)batch, in_place)).first;
+        work.reserve(it->second->work_bytes());
+        it->second->exec(const_cast<void*>(in), out, work.get(), as_stream(stream));
     });
 }
 

@@ -1,0 +1,91 @@
+// Hand-written multi-pass FFT for gfx950 (fft_engine.hip / fft_kernel.h).
+//
+// A transform of length n = n1*n2*...*np (p = 2..4) runs as p "passes".  One
+// workgroup of a pass owns a tile of W = 16 adjacent lines x L points: it loads the
+// tile in 128-byte coalesced segments, runs a mixed-radix decimation-in-frequency
+// FFT along L entirely in LDS, applies the inter-pass twiddle and writes the tile
+// back, again in 128-byte segments.  Each pass reads and writes every element
+// exactly once; there are no separate transpose or twiddle kernels (rocFFT spends
+// 5-6 launches on the same lengths, profiles/r01_a_*).
+//
+// Index maps (decimation in time across passes, natural order in and out), with
+// m_t = n_{t+1} * ... * n_p:
+//   pass t < p : lines (k_1..k_{t-1}; j in [0, m_t)), point l at  sum k_s m_s + l m_t + j,
+//                written back in place (l -> k_t) times W_n^((n / m_{t-1}) j k_t);
+//   pass p     : lines (k_1..k_{p-1}), contiguous n_p points; output k_p lands at
+//                k_1 + n_1 (k_2 + n_2 (... + n_{p-1} k_p)); tiles take 16 adjacent k_1.
+#pragma once
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace rcfm {
+
+constexpr int kFftTileW = 16;      // lines per tile: 16 x 8 B = one 128-byte segment
+constexpr int kFftMaxStages = 8;
+constexpr int kFftMaxPasses = 4;
+constexpr int kFftMaxL = 512;      // longest in-LDS transform (tile + tables < 80 KiB: 2 workgroups per CU)
+
+// One pass.  Lines are indexed by (o1, o2, i): a tile covers 16 adjacent i.
+//   input  point l of a line: in [batch*in_batch  + o1*in_o1  + o2*in_o2  + i*in_i  + l*in_l ]
+//   output point k of a line: out[batch*out_batch + o1*out_o1 + o2*out_o2 + i*out_i + k*out_k]
+//   multiplied by W_n^((o1*tw_o1 + o2*tw_o2 + i*tw_i) * k) when has_twiddle (the product is < n).
+struct FftPass {
+    int L;
+    int nstages;
+    int radix[kFftMaxStages];
+    int64_t n_o1, n_o2, n_inner;
+    int64_t in_o1, in_o2, in_i, in_l;
+    int64_t out_o1, out_o2, out_i, out_k;
+    int64_t tw_o1, tw_o2, tw_i;
+    int has_twiddle;
+    int load_along_l;   // 1: a line is contiguous in memory (in_l == 1): lanes run along l when loading
+};
+
+struct FftPlanDesc {
+    int64_t n;
+    int npass;
+    int fine_bits;      // W_n^e = coarse[e >> fine_bits] * cis(-2 pi (e & mask) / n)
+    FftPass pass[kFftMaxPasses];
+};
+
+// Factorises n (radices 2, 3, 4, 5, 6, 8, 10) into passes.  Returns false when n has
+// another prime factor, is too small to tile, or does not fit 4 passes; callers then
+// fall back to rocFFT.
+// max_l (<= kFftMaxL, 0 = default) caps the per-pass length; tests use it to force deep plans.
+bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l = 0);
+
+// Device-side view of one pass, handed to the kernel by value.
+struct FftPassDev {
+    FftPass p;
+    const float2* stage_tw;   // W_L^e, e in [0, L)
+    const uint16_t* pos;      // LDS row that holds output k after the in-place DIF stages
+    const float2* coarse;     // W_n^(c << fine_bits)
+    float fine_step;          // 2 pi / n
+    int fine_bits;
+    int64_t in_batch, out_batch;
+};
+
+class FftEngine {
+   public:
+    explicit FftEngine(int64_t n);
+    const FftPlanDesc& desc() const { return desc_; }
+    int npass() const { return desc_.npass; }
+    // Unnormalised c2c transform of `batch` contiguous length-n signals (distance n).
+    // `tmp` holds batch*n complex values; in == out is allowed, tmp must be distinct.
+    // inverse = conjugate transform (no 1/n); every output is multiplied by `scale`.
+    void c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
+             hipStream_t stream) const;
+    FftPassDev pass_dev(int t, int64_t in_batch, int64_t out_batch) const;
+    static size_t lds_bytes(int L);
+    static dim3 grid(const FftPass& p, int batch);
+
+   private:
+    FftPlanDesc desc_;
+    DeviceBuffer stage_tw_[kFftMaxPasses];
+    DeviceBuffer pos_[kFftMaxPasses];
+    DeviceBuffer coarse_;
+};
+
+}  // namespace rcfm

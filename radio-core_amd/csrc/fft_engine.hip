@@ -1,0 +1,235 @@
+#include "fft_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <vector>
+
+#include "fft_kernel.h"
+
+namespace rcfm {
+
+namespace {
+
+constexpr double kTwoPi = 6.28318530717958647692;
+
+// Largest-radix-first factorisation of an LDS transform length.
+bool choose_radices(int L, int* radix, int* nstages) {
+    static const int kRadix[] = {10, 8, 6, 5, 4, 3, 2};
+    int rem = L, ns = 0;
+    while (rem > 1) {
+        bool found = false;
+        for (int r : kRadix) {
+            if (rem % r == 0) {
+                if (ns == kFftMaxStages) return false;
+                radix[ns++] = r;
+                rem /= r;
+                found = true;
+                break;
+            }
+        }
+        if (!found) return false;
+    }
+    *nstages = ns;
+    return ns > 0;
+}
+
+bool smooth235(int64_t n) {
+    for (int p : {2, 3, 5})
+        while (n % p == 0) n /= p;
+    return n == 1;
+}
+
+// Split n into `np` factors <= kFftMaxL, each >= 16, as balanced as possible, preferring
+// factorizations whose tiled dimensions (n_1 and m_1..m_{p-1}) are multiples of 16.
+bool split(int64_t n, int np, int max_l, int64_t* f) {
+    std::vector<int64_t> divs;
+    for (int64_t d = 16; d <= max_l; ++d)
+        if (n % d == 0) divs.push_back(d);
+    double best = 1e300;
+    bool ok = false;
+    int64_t cur[kFftMaxPasses];
+    // depth-first over divisor choices (np <= 4, |divs| small)
+    std::function<void(int, int64_t)> rec = [&](int t, int64_t rem) {
+        if (t == np - 1) {
+            if (rem < 16 || rem > max_l) return;
+            cur[t] = rem;
+            int64_t mx = 0, mn = 1 << 30;
+            for (int i = 0; i < np; ++i) {
+                mx = std::max(mx, cur[i]);
+                mn = std::min(mn, cur[i]);
+            }
+            double cost = (double)mx / (double)mn;
+            // tail tiles waste lanes: penalise tiled extents that are not multiples of 16
+            auto tail = [](int64_t extent) {
+                const int64_t tiles = (extent + 15) / 16;
+                return (double)(tiles * 16) / (double)extent - 1.0;
+            };
+            int64_t m = n;
+            for (int i = 0; i < np - 1; ++i) {
+                m /= cur[i];
+                cost += 4.0 * tail(m);        // pass i tiles over j in [0, m_i)
+            }
+            cost += 4.0 * tail(cur[0]);       // the last pass tiles over k_1
+            if (cost < best) {
+                best = cost;
+                ok = true;
+                for (int i = 0; i < np; ++i) f[i] = cur[i];
+            }
+            return;
+        }
+        for (int64_t d : divs) {
+            if (rem % d) continue;
+            cur[t] = d;
+            rec(t + 1, rem / d);
+        }
+    };
+    rec(0, n);
+    return ok;
+}
+
+}  // namespace
+
+bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l) {
+    if (max_l <= 0 || max_l > kFftMaxL) max_l = kFftMaxL;
+    if (n < 256 || n >= (int64_t(1) << 32) || !smooth235(n)) return false;
+    int np = 0;
+    int64_t f[kFftMaxPasses];
+    for (int cand = 2; cand <= kFftMaxPasses; ++cand) {
+        if (split(n, cand, max_l, f)) {
+            np = cand;
+            break;
+        }
+    }
+    if (!np) return false;
+    FftPlanDesc d{};
+    d.n = n;
+    d.npass = np;
+    // fine angle below 0.03 rad: 2 pi F / n <= 0.03
+    d.fine_bits = 0;
+    while ((double)(int64_t(2) << d.fine_bits) * kTwoPi / (double)n <= 0.03) ++d.fine_bits;
+    // m[t] = n_{t+1} * ... * n_p  (m[0] = n / n_1)
+    int64_t m[kFftMaxPasses + 1];
+    m[np - 1] = 1;
+    for (int t = np - 2; t >= 0; --t) m[t] = m[t + 1] * f[t + 1];
+    for (int t = 0; t < np; ++t) {
+        FftPass& p = d.pass[t];
+        p = FftPass{};
+        p.L = (int)f[t];
+        if (!choose_radices(p.L, p.radix, &p.nstages)) return false;
+        p.n_o1 = p.n_o2 = 1;
+        if (t < np - 1) {
+            // lines (k_1 .. k_t-1 ; j in [0, m_t)): strided columns, written back in place
+            p.n_inner = m[t];
+            p.in_i = p.out_i = 1;
+            p.in_l = p.out_k = m[t];
+            if (t >= 1) {
+                p.n_o1 = f[0];
+                p.in_o1 = p.out_o1 = m[0];
+            }
+            if (t >= 2) {
+                p.n_o2 = f[1];
+                p.in_o2 = p.out_o2 = m[1];
+            }
+            p.has_twiddle = 1;
+            p.tw_i = n / (m[t] * f[t]);   // n / m_{t-1}
+            p.load_along_l = 0;
+        } else {
+            // last pass: lines (k_1 .. k_p-1) are contiguous runs of n_p points; tiles take 16
+            // adjacent k_1; output k_p lands at k_1 + n_1 (k_2 + n_2 (k_3 + n_3 k_p))
+            p.n_inner = f[0];
+            p.in_i = m[0];
+            p.in_l = 1;
+            p.out_i = 1;
+            int64_t stride = f[0];
+            if (np >= 3) {
+                p.n_o1 = f[1];
+                p.in_o1 = m[1];
+                p.out_o1 = stride;
+                stride *= f[1];
+            }
+            if (np >= 4) {
+                p.n_o2 = f[2];
+                p.in_o2 = m[2];
+                p.out_o2 = stride;
+                stride *= f[2];
+            }
+            p.out_k = stride;
+            p.has_twiddle = 0;
+            p.load_along_l = 1;
+        }
+    }
+    *out = d;
+    return true;
+}
+
+size_t FftEngine::lds_bytes(int L) { return (size_t)L * (kFftTileW * sizeof(float2) + sizeof(float2) + sizeof(uint16_t)); }
+
+dim3 FftEngine::grid(const FftPass& p, int batch) {
+    const int64_t tiles = p.n_o1 * p.n_o2 * ((p.n_inner + kFftTileW - 1) / kFftTileW);
+    return dim3((unsigned)tiles, (unsigned)batch, 1);
+}
+
+FftEngine::FftEngine(int64_t n) {
+    RC_REQUIRE(fft_plan_describe(n, &desc_), RCFM_ERR_ARG, "length not supported by the FFT engine");
+    for (int t = 0; t < desc_.npass; ++t) {
+        const FftPass& p = desc_.pass[t];
+        std::vector<float2> tw(p.L);
+        for (int e = 0; e < p.L; ++e) {
+            const double a = -kTwoPi * (double)e / (double)p.L;
+            tw[e] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        stage_tw_[t].upload(tw.data(), tw.size() * sizeof(float2));
+        // slot of output k after the in-place DIF stages: digits of k, least significant first,
+        // weigh L/r_1, L/(r_1 r_2), ...
+        std::vector<uint16_t> pos(p.L);
+        for (int k = 0; k < p.L; ++k) {
+            int rem = k, weight = p.L, slot = 0;
+            for (int s = 0; s < p.nstages; ++s) {
+                weight /= p.radix[s];
+                slot += (rem % p.radix[s]) * weight;
+                rem /= p.radix[s];
+            }
+            pos[k] = (uint16_t)slot;
+        }
+        pos_[t].upload(pos.data(), pos.size() * sizeof(uint16_t));
+    }
+    const int64_t F = int64_t(1) << desc_.fine_bits;
+    const int64_t nc = (n + F - 1) / F;
+    std::vector<float2> coarse(nc);
+    for (int64_t c = 0; c < nc; ++c) {
+        const double a = -kTwoPi * (double)(c * F) / (double)n;
+        coarse[c] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    coarse_.upload(coarse.data(), coarse.size() * sizeof(float2));
+}
+
+FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch) const {
+    FftPassDev d;
+    d.p = desc_.pass[t];
+    d.stage_tw = stage_tw_[t].as<float2>();
+    d.pos = pos_[t].as<uint16_t>();
+    d.coarse = coarse_.as<float2>();
+    d.fine_step = (float)(kTwoPi / (double)desc_.n);
+    d.fine_bits = desc_.fine_bits;
+    d.in_batch = in_batch;
+    d.out_batch = out_batch;
+    return d;
+}
+
+void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
+                    hipStream_t stream) const {
+    if (batch <= 0) return;
+    const int np = desc_.npass;
+    const int64_t n = desc_.n;
+    for (int t = 0; t < np; ++t) {
+        const bool first = (t == 0), last = (t == np - 1);
+        const float2* src = first ? in : tmp;
+        float2* dst = last ? out : tmp;
+        fftk::LoadPlain ld{src, (first && inverse) ? 1 : 0};
+        fftk::StorePlain st{dst, (last && inverse) ? 1 : 0, last ? scale : 1.0f};
+        fftk::launch_fft_pass(pass_dev(t, n, n), batch, ld, st, stream);
+    }
+}
+
+}  // namespace rcfm

@@ -58,11 +58,31 @@ SIGNATURES = {
     "rcfm_hilbert": [_i, _i, _vp, _vp, _vp],
     "rcfm_pll_phase": [_vp, _sz, _dbl, _i, _vp, _vp],
     "rcfm_discriminator": [_i, _i, _vp, _vp, _vp],
+    "rcfm_fft_describe": [_i64, _i, _vp],
+    "rcfm_fft_c2c": [_i64, _i, _i, _vp, _vp, _vp],
+    "rcfm_fft_c2c_rocfft": [_i64, _i, _i, _vp, _vp, _vp],
     "rcfm_profile_stage_count": [],
     "rcfm_profile_enable": [ctypes.c_uint64],
     "rcfm_profile_reset": [],
     "rcfm_profile_read": [_i, ctypes.POINTER(_dbl), ctypes.POINTER(_i64)],
 }
+
+
+
+class FftPass(ctypes.Structure):
+    """rcfm_fft_pass (include/rcfm.h)."""
+    _fields_ = [("L", ctypes.c_int32), ("nstages", ctypes.c_int32), ("radix", ctypes.c_int32 * 8),
+                ("n_o1", _i64), ("n_o2", _i64), ("n_inner", _i64),
+                ("in_o1", _i64), ("in_o2", _i64), ("in_i", _i64), ("in_l", _i64),
+                ("out_o1", _i64), ("out_o2", _i64), ("out_i", _i64), ("out_k", _i64),
+                ("tw_o1", _i64), ("tw_o2", _i64), ("tw_i", _i64),
+                ("has_twiddle", ctypes.c_int32), ("load_along_l", ctypes.c_int32)]
+
+
+class FftPlan(ctypes.Structure):
+    """rcfm_fft_plan (include/rcfm.h)."""
+    _fields_ = [("n", _i64), ("npass", ctypes.c_int32), ("fine_bits", ctypes.c_int32), ("passes", FftPass * 4)]
+
 
 _lib = None
 _torch = None

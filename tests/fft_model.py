@@ -1,0 +1,86 @@
+"""numpy model of librcfm's multi-pass FFT, driven by the plan the library describes.
+
+Mirrors radio-core_amd/csrc/fft_kernel.h step by step (tile load, in-place
+decimation-in-frequency stages with their stage twiddles, digit-reversed read-out,
+inter-pass twiddle, strided store) so the planner and every index formula are
+checked on the CPU against numpy.fft; the GPU tests then only have to show that the
+kernel executes this model.
+"""
+
+import ctypes
+
+import numpy as np
+
+
+def describe(n, max_l=0):
+    from radiocore._internal import hip
+    lib = hip.load_library()
+    plan = hip.FftPlan()
+    rc = lib.rcfm_fft_describe(ctypes.c_int64(n), max_l, ctypes.byref(plan))
+    return plan if rc == 0 else None
+
+
+def lds_fft(tile, radices):
+    """tile: [L, w] complex; in-place DIF stages, then read-out through pos[]."""
+    L = tile.shape[0]
+    x = tile.astype(np.complex128).copy()
+    mt = L
+    for r in radices:
+        m = mt // r
+        step = L // mt
+        for g in range(L // mt):
+            for kp in range(m):
+                rows = g * mt + kp + m * np.arange(r)
+                v = x[rows]                                           # [r, w]
+                q = np.arange(r)
+                dft = np.exp(-2j * np.pi * np.outer(q, q) / r)         # y[q'] = sum_q x[q] W_r^(q q')
+                y = dft @ v
+                tw = np.exp(-2j * np.pi * (q * kp * step) / L)         # stage_tw[q' * kp * step]
+                x[rows] = y * tw[:, None]
+        mt = m
+    pos = np.zeros(L, np.int64)
+    for k in range(L):
+        rem, weight, slot = k, L, 0
+        for r in radices:
+            weight //= r
+            slot += (rem % r) * weight
+            rem //= r
+        pos[k] = slot
+    return x[pos]
+
+
+def run_pass(p, n, src, dst):
+    L = p.L
+    radices = [p.radix[s] for s in range(p.nstages)]
+    W = 16
+    for o1 in range(p.n_o1):
+        for o2 in range(p.n_o2):
+            for i0 in range(0, p.n_inner, W):
+                wv = min(W, p.n_inner - i0)
+                i = i0 + np.arange(wv)
+                l = np.arange(L)
+                in_addr = o1 * p.in_o1 + o2 * p.in_o2 + i[None, :] * p.in_i + l[:, None] * p.in_l
+                tile = src[in_addr]
+                out = lds_fft(tile, radices)
+                k = np.arange(L)
+                if p.has_twiddle:
+                    line = o1 * p.tw_o1 + o2 * p.tw_o2 + i * p.tw_i
+                    e = line[None, :] * k[:, None]
+                    assert e.max() < n                              # the kernel relies on this: no modulo
+                    out = out * np.exp(-2j * np.pi * e / n)
+                out_addr = o1 * p.out_o1 + o2 * p.out_o2 + i[None, :] * p.out_i + k[:, None] * p.out_k
+                dst[out_addr] = out
+
+
+def model_fft(x, plan):
+    n = plan.n
+    tmp = np.zeros(n, np.complex128)
+    out = np.zeros(n, np.complex128)
+    for t in range(plan.npass):
+        p = plan.passes[t]
+        src = x if t == 0 else tmp
+        dst = out if t == plan.npass - 1 else tmp
+        if src is dst:
+            src = src.copy()
+        run_pass(p, n, np.asarray(src, np.complex128), dst)
+    return out

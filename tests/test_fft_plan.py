@@ -1,0 +1,53 @@
+"""CPU: the FFT engine's planner and index maps (no GPU): the plan librcfm describes,
+executed by the numpy model of its kernel, equals numpy.fft."""
+
+import numpy as np
+import pytest
+
+import fft_model
+
+
+def test_lengths_of_the_hot_path_are_planned():
+    for n, npass in [(240000, 2), (48000, 2), (12500, 2), (8000, 2), (60000, 2), (12000, 2),
+                     (10_000_000, 3), (100_000_000, 3), (240_000_000, 4), (600000, 3), (256000, 2)]:
+        plan = fft_model.describe(n)
+        assert plan is not None, n
+        assert plan.npass == npass, (n, plan.npass)
+        prod = 1
+        for t in range(plan.npass):
+            p = plan.passes[t]
+            prod *= p.L
+            r = 1
+            for s in range(p.nstages):
+                assert p.radix[s] in (2, 3, 4, 5, 6, 8, 10)
+                r *= p.radix[s]
+            assert r == p.L and 16 <= p.L <= 512
+        assert prod == n
+
+
+@pytest.mark.parametrize("n", [100, 24001, 7 * 4096, 255])
+def test_unsupported_lengths_are_refused(n):
+    assert fft_model.describe(n) is None
+
+
+@pytest.mark.parametrize("n", [256, 1000, 4096, 6000, 12500, 24000, 32768, 60000])
+def test_model_of_the_plan_is_an_fft(n):
+    plan = fft_model.describe(n)
+    assert plan is not None
+    r = np.random.default_rng(n)
+    x = r.standard_normal(n) + 1j * r.standard_normal(n)
+    got = fft_model.model_fft(x, plan)
+    want = np.fft.fft(x)
+    assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("n,max_l,npass", [(512000, 0, 3), (16 * 16 * 20, 20, 3), (16 * 16 * 16 * 20, 20, 4),
+                                           (18 * 20 * 16 * 16, 20, 4)])
+def test_deep_plans(n, max_l, npass):
+    plan = fft_model.describe(n, max_l)
+    assert plan is not None and plan.npass == npass
+    r = np.random.default_rng(n)
+    x = r.standard_normal(n) + 1j * r.standard_normal(n)
+    got = fft_model.model_fft(x, plan)
+    want = np.fft.fft(x)
+    assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))

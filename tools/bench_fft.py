@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""A/B timing of librcfm's FFT engine vs rocFFT on the hot-path lengths (GPU box)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
+import torch  # noqa: E402
+
+from radiocore._internal import hip  # noqa: E402
+
+
+def time_fn(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    lib = hip.lib()
+    hip.torch()
+    cases = [(240000, 16, 20), (240000, 64, 10), (240000, 256, 5), (48000, 64, 20), (12500, 1024, 10),
+             (10_000_000, 1, 10), (100_000_000, 1, 5), (240_000_000, 1, 5)]
+    if len(sys.argv) > 1:
+        cases = [c for c in cases if str(c[0]) in sys.argv[1:]]
+    for n, batch, reps in cases:
+        x = torch.view_as_complex(torch.randn(batch * n, 2, device="cuda"))
+        y = torch.empty_like(x)
+        for name, fn in (("engine", lib.rcfm_fft_c2c), ("rocfft", lib.rcfm_fft_c2c_rocfft)):
+            ms = time_fn(lambda: hip.check(fn(n, batch, 0, hip.ptr(x), hip.ptr(y), hip.stream())), reps)
+            gb = 16.0 * n * batch / 1e9
+            print("n=%-10d batch=%-5d %-7s %9.3f ms   %7.2f TB/s algorithmic (16 B/point)" %
+                  (n, batch, name, ms, gb / ms), flush=True)
+        del x, y
+
+
+if __name__ == "__main__":
+    main()
