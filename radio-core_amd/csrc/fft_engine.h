@@ -65,6 +65,7 @@ struct FftPassDev {
     float fine_step;          // 2 pi / n
     int fine_bits;
     int64_t in_batch, out_batch;
+    int debug;                // RCFM_FFT_DEBUG bit mask: timing experiments only (wrong results)
 };
 
 class FftEngine {
@@ -80,6 +81,7 @@ class FftEngine {
     FftPassDev pass_dev(int t, int64_t in_batch, int64_t out_batch) const;
     static size_t lds_bytes(int L);
     static dim3 grid(const FftPass& p, int batch);
+    static int compute_units();   // CUs of the current device (256 on MI355X)
 
    private:
     FftPlanDesc desc_;

@@ -34,6 +34,16 @@ bool choose_radices(int L, int* radix, int* nstages) {
     return ns > 0;
 }
 
+bool is_fast_length(int64_t L) {
+    switch (L) {
+#define RCFM_CASE(LEN, A, B, C, D) case LEN:
+        RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+#undef RCFM_CASE
+        return true;
+        default: return false;
+    }
+}
+
 bool smooth235(int64_t n) {
     for (int p : {2, 3, 5})
         while (n % p == 0) n /= p;
@@ -60,6 +70,8 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
                 mn = std::min(mn, cur[i]);
             }
             double cost = (double)mx / (double)mn;
+            for (int i = 0; i < np; ++i)
+                if (!is_fast_length(cur[i])) cost += 3.0;   // no compile-time specialised kernel
             // tail tiles waste lanes: penalise tiled extents that are not multiples of 16
             auto tail = [](int64_t extent) {
                 const int64_t tiles = (extent + 15) / 16;
@@ -69,8 +81,10 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
             for (int i = 0; i < np - 1; ++i) {
                 m /= cur[i];
                 cost += 4.0 * tail(m);        // pass i tiles over j in [0, m_i)
+                if (m % 16) cost += 1.0;      // its 128-byte read segments would straddle cache lines
             }
             cost += 4.0 * tail(cur[0]);       // the last pass tiles over k_1
+            if (cur[0] % 16) cost += 0.3;     // misaligned (but sector-aligned) write segments
             if (cost < best) {
                 best = cost;
                 ok = true;
@@ -170,6 +184,15 @@ dim3 FftEngine::grid(const FftPass& p, int batch) {
     return dim3((unsigned)tiles, (unsigned)batch, 1);
 }
 
+int FftEngine::compute_units() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
 FftEngine::FftEngine(int64_t n) {
     RC_REQUIRE(fft_plan_describe(n, &desc_), RCFM_ERR_ARG, "length not supported by the FFT engine");
     for (int t = 0; t < desc_.npass; ++t) {
@@ -214,6 +237,11 @@ FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch) const
     d.fine_bits = desc_.fine_bits;
     d.in_batch = in_batch;
     d.out_batch = out_batch;
+    static const int dbg = [] {
+        const char* e = std::getenv("RCFM_FFT_DEBUG");
+        return e ? std::atoi(e) : 0;
+    }();
+    d.debug = dbg;
     return d;
 }
 
