@@ -13,6 +13,7 @@
 #include "common.h"
 #include "fft_engine.h"
 #include "fft_plan.h"
+#include "fused_passes.h"
 #include "kernels.h"
 
 namespace rcfm {
@@ -235,6 +236,15 @@ using namespace rcfm;
 // handles
 // ---------------------------------------------------------------------------
 
+// RCFM_FFT=rocfft routes every transform through rocFFT (A/B runs and a safety net).
+static bool use_engine() {
+    static const bool v = [] {
+        const char* e = std::getenv("RCFM_FFT");
+        return !(e && std::string(e) == "rocfft");
+    }();
+    return v;
+}
+
 struct rcfm_tuner_s {
     int64_t n = 0;
     int nch = 0;
@@ -243,11 +253,15 @@ struct rcfm_tuner_s {
     DeviceBuffer roll_dev;
     DeviceBuffer X;
     DeviceBuffer work;
-    std::unique_ptr<FftPlan> forward;
+    std::unique_ptr<FftPlan> forward;          // rocFFT fallback for lengths outside the engine
+    std::unique_ptr<FftEngine> forward_engine;
+    DeviceBuffer forward_tmp;                  // engine: the last pass cannot run in place
+    DeviceBuffer band_tmp;
     bool loaded = false;
     struct Band {
         ResampleGeom geom;
         PlanCache inverse;
+        std::unique_ptr<FftEngine> engine;
     };
     std::map<int32_t, std::unique_ptr<Band>> bands;
 
@@ -256,6 +270,8 @@ struct rcfm_tuner_s {
         if (it == bands.end()) {
             auto nb = std::make_unique<Band>();
             nb->geom.build(n, b, 0.5 /* hann */, true);
+            FftPlanDesc probe;
+            if (use_engine() && fft_plan_describe(b, &probe)) nb->engine = std::make_unique<FftEngine>(b);
             it = bands.emplace(b, std::move(nb)).first;
         }
         return *it->second;
@@ -269,10 +285,18 @@ struct rcfm_tuner_s {
         for (int i = 0; i < count; ++i)
             RC_REQUIRE(bw[first + i] == B, RCFM_ERR_ARG, "channels of one rcfm_tuner_run range must share a bandwidth");
         Band& bd = band(B);
+        const ResampleGeom& g = bd.geom;
+        if (bd.engine) {
+            // gather + window ride on the first pass of the inverse FFT (fused_passes.h)
+            band_tmp.reserve((size_t)count * B * sizeof(float2));
+            TunerGather tg{X.as<float2>(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode};
+            StageTimer tm(ST_TUNER_IFFT, s);
+            fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s);
+            return;
+        }
         size_t need = 0;
         FftPlan& inv = bd.inverse.get(FftKind::C2C_INVERSE, (size_t)B, count, true, need);
         work.reserve(need);
-        const ResampleGeom& g = bd.geom;
         {
             StageTimer tm(ST_TUNER_GATHER, s);
             launch_spectrum_c2c(X.as<float2>(), 0, n, roll_dev.as<int64_t>() + first, out, B, count,
@@ -296,12 +320,14 @@ struct rcfm_demod_s {
     float side_tap = 0.23f;
     ResampleGeom geom;   // B -> A, real, Hamming
     PlanCache r2c_B, c2c_inv_B, c2c_fwd_B, c2c_inv_A, c2r_A;
-    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial;
+    std::unique_ptr<FftEngine> eng_B, eng_A;   // both set: the engine path with fused passes
+    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA;
     int tiles = 0;
 
     void alloc() {
         const size_t c = (size_t)chunk;
         tiles = fir_tiles(A);
+
         if (kind == RCFM_WBFM) {
             buf_m.reset(c * B * sizeof(float));
             buf_p.reset(c * B * sizeof(float));
@@ -315,6 +341,17 @@ struct rcfm_demod_s {
             if (kind == RCFM_MFM) buf_v.reset(c * A * sizeof(float));
         }
         if (kind != RCFM_FM) partial.reset((size_t)chunk * ch * tiles * sizeof(float));
+        FftPlanDesc probe;
+        if (use_engine() && fft_plan_describe(B, &probe) && fft_plan_describe(A, &probe)) {
+            eng_B = std::make_unique<FftEngine>(B);
+            eng_A = std::make_unique<FftEngine>(A);
+            buf_T.reset(c * B * sizeof(float2));
+            buf_TA.reset(c * A * sizeof(float2));
+            if (kind != RCFM_WBFM) {
+                buf_Z.reset(c * B * sizeof(float2));   // full spectrum of the discriminator output
+                buf_V.reset(c * A * sizeof(float2));   // Hermitian audio spectrum
+            }
+        }
     }
 
     void reset_state(hipStream_t s) {
@@ -328,11 +365,14 @@ struct rcfm_demod_s {
     void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s) {
         size_t need = 0;
         if (kind == RCFM_WBFM) {
-            FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);
-            FftPlan& f2 = c2c_inv_B.get(FftKind::C2C_INVERSE, B, cnt, true, need);
-            FftPlan& f3 = c2c_fwd_B.get(FftKind::C2C_FORWARD, B, cnt, true, need);
-            FftPlan& f4 = c2c_inv_A.get(FftKind::C2C_INVERSE, A, cnt, true, need);
-            work.reserve(need);
+            FftPlan* pf[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (!eng_B) {
+                pf[0] = &r2c_B.get(FftKind::R2C, B, cnt, false, need);
+                pf[1] = &c2c_inv_B.get(FftKind::C2C_INVERSE, B, cnt, true, need);
+                pf[2] = &c2c_fwd_B.get(FftKind::C2C_FORWARD, B, cnt, true, need);
+                pf[3] = &c2c_inv_A.get(FftKind::C2C_INVERSE, A, cnt, true, need);
+                work.reserve(need);
+            }
             float* m = buf_m.as<float>();
             float* p = buf_p.as<float>();
             float2* P = buf_P.as<float2>();
@@ -343,10 +383,50 @@ struct rcfm_demod_s {
                 StageTimer tm(ST_PILOT, s);
                 launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
             }
+            if (eng_B) {
+                float2* T = buf_T.as<float2>();
+                float2* TA = buf_TA.as<float2>();
+                {   // wbfm.py:80 / pll.py:34: spectrum of the pilot band
+                    StageTimer tm(ST_FFT_REAL_B, s);
+                    fused_real_fft(*eng_B, p, Z, T, cnt, -1, s);
+                }
+                {   // one-sided mask -> inverse FFT -> 38 kHz carrier, L-R, stereo matrix (wbfm.py:83,86-87)
+                    StageTimer tm(ST_IFFT_B, s);
+                    fused_hilbert_ifft_mix(*eng_B, Z, m, Z, T, cnt, s);
+                }
+                {   // both stereo legs in one complex FFT; only |k| <= A/2 survives the decimation
+                    StageTimer tm(ST_FFT_B, s);
+                    fused_fft_pruned(*eng_B, Z, Z, T, cnt, std::min(A, B) / 2, s);
+                }
+                {
+                    StageTimer tm(ST_AUDIO_SPECTRUM, s);
+                    launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
+                                         geom.nyq_factor, geom.scale, s);
+                }
+                {
+                    StageTimer tm(ST_IFFT_A, s);
+                    eng_A->c2c(V, V, TA, cnt, true, 1.0f, s);   // -> [cnt][A][2] float32, L/R interleaved
+                }
+                float* st = state.as<float>() + (size_t)first * ch * 50;
+                {
+                    StageTimer tm(ST_DEEMPH, s);
+                    launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
+                               partial.as<float>(), s);
+                }
+                {
+                    StageTimer tm(ST_DEEMPH_STATE, s);
+                    launch_fir_state(reinterpret_cast<float*>(V), A, 2, cnt, taps.as<float>(), 51, st, s);
+                }
+                {
+                    StageTimer tm(ST_DC_CLIP, s);
+                    launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles, s);
+                }
+                return;
+            }
             // wbfm.py:80 / pll.py:34  analytic signal of the pilot
             {
                 StageTimer tm(ST_FFT_REAL_B, s);
-                f1.exec(p, P, work.get(), s);
+                pf[0]->exec(p, P, work.get(), s);
             }
             {
                 StageTimer tm(ST_HILBERT_MASK, s);
@@ -354,7 +434,7 @@ struct rcfm_demod_s {
             }
             {
                 StageTimer tm(ST_IFFT_B, s);
-                f2.exec(Z, Z, work.get(), s);
+                pf[1]->exec(Z, Z, work.get(), s);
             }
             // wbfm.py:83,86-87  38 kHz carrier, L-R, stereo matrix; both legs packed in one complex signal
             {
@@ -363,7 +443,7 @@ struct rcfm_demod_s {
             }
             {
                 StageTimer tm(ST_FFT_B, s);
-                f3.exec(Z, Z, work.get(), s);
+                pf[2]->exec(Z, Z, work.get(), s);
             }
             {
                 StageTimer tm(ST_AUDIO_SPECTRUM, s);
@@ -372,7 +452,7 @@ struct rcfm_demod_s {
             }
             {
                 StageTimer tm(ST_IFFT_A, s);
-                f4.exec(V, V, work.get(), s);   // -> [cnt][A][2] float32, L/R interleaved
+                pf[3]->exec(V, V, work.get(), s);   // -> [cnt][A][2] float32, L/R interleaved
             }
             // wbfm.py:90-100  de-emphasis (separate L/R state), joint DC removal, clip
             float* st = state.as<float>() + (size_t)first * ch * 50;
@@ -391,17 +471,50 @@ struct rcfm_demod_s {
             }
             return;
         }
-        FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);
-        FftPlan& f2 = c2r_A.get(FftKind::C2R, A, cnt, false, need);
-        work.reserve(need);
         float* d = buf_m.as<float>();
-        float2* D = buf_P.as<float2>();
-        float2* Y = buf_V.as<float2>();
         // fm.py:60-66  discriminator, then Decimate(B -> A)
         {
             StageTimer tm(ST_DISC, s);
             launch_discriminator(iq, d, B, cnt, s);
         }
+        if (eng_B) {
+            float2* Dfull = buf_Z.as<float2>();
+            float2* Yfull = buf_V.as<float2>();
+            {
+                StageTimer tm(ST_FFT_REAL_B, s);
+                fused_real_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
+            }
+            {
+                StageTimer tm(ST_AUDIO_SPECTRUM, s);
+                launch_spectrum_real_full(Dfull, B, Yfull, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
+                                          geom.nyq_factor, geom.scale, s);
+            }
+            float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
+            {
+                StageTimer tm(ST_IFFT_A, s);
+                fused_ifft_real_out(*eng_A, Yfull, dst, buf_TA.as<float2>(), cnt, 1.0f, s);
+            }
+            if (kind == RCFM_FM) return;
+            float* st = state.as<float>() + (size_t)first * 50;
+            {
+                StageTimer tm(ST_DEEMPH, s);
+                launch_fir(dst, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
+            }
+            {
+                StageTimer tm(ST_DEEMPH_STATE, s);
+                launch_fir_state(dst, A, 1, cnt, taps.as<float>(), 51, st, s);
+            }
+            {
+                StageTimer tm(ST_DC_CLIP, s);
+                launch_dc_clip(audio, A, 1, cnt, partial.as<float>(), tiles, s);
+            }
+            return;
+        }
+        FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);
+        FftPlan& f2 = c2r_A.get(FftKind::C2R, A, cnt, false, need);
+        work.reserve(need);
+        float2* D = buf_P.as<float2>();
+        float2* Y = buf_V.as<float2>();
         {
             StageTimer tm(ST_FFT_REAL_B, s);
             f1.exec(d, D, work.get(), s);
@@ -516,8 +629,14 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
         }
         if (nch) t->roll_dev.upload(t->roll.data(), sizeof(int64_t) * nch);
         t->X.reset(sizeof(float2) * (size_t)n);
-        t->forward = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, 1, false);
-        t->work.reserve(t->forward->work_bytes());
+        FftPlanDesc probe;
+        if (use_engine() && fft_plan_describe(n, &probe)) {
+            t->forward_engine = std::make_unique<FftEngine>(n);
+            t->forward_tmp.reset(sizeof(float2) * (size_t)n);
+        } else {
+            t->forward = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, 1, false);
+            t->work.reserve(t->forward->work_bytes());
+        }
         *out = t.release();
     });
 }
@@ -525,10 +644,15 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
 int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
     return guarded([&] {
         RC_REQUIRE(t && x, RCFM_ERR_ARG, "NULL argument");
-        t->work.reserve(t->forward->work_bytes());
         {
             StageTimer tm(ST_TUNER_FFT, as_stream(stream));
-            t->forward->exec(const_cast<void*>(x), t->X.get(), t->work.get(), as_stream(stream));
+            if (t->forward_engine) {
+                t->forward_engine->c2c(static_cast<const float2*>(x), t->X.as<float2>(), t->forward_tmp.as<float2>(),
+                                       1, false, 1.0f, as_stream(stream));
+            } else {
+                t->work.reserve(t->forward->work_bytes());
+                t->forward->exec(const_cast<void*>(x), t->X.get(), t->work.get(), as_stream(stream));
+            }
         }
         t->loaded = true;
     });

@@ -250,13 +250,24 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
     if (batch <= 0) return;
     const int np = desc_.npass;
     const int64_t n = desc_.n;
+    using namespace fftk;
     for (int t = 0; t < np; ++t) {
         const bool first = (t == 0), last = (t == np - 1);
         const float2* src = first ? in : tmp;
-        float2* dst = last ? out : tmp;
-        fftk::LoadPlain ld{src, (first && inverse) ? 1 : 0};
-        fftk::StorePlain st{dst, (last && inverse) ? 1 : 0, last ? scale : 1.0f};
-        fftk::launch_fft_pass(pass_dev(t, n, n), batch, ld, st, stream);
+        const FftPassDev dev = pass_dev(t, n, n);
+        if (last) {
+            LoadPlainT<false> ld{src};
+            if (inverse)
+                launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<true>{out, scale}, stream);
+            else
+                launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<false>{out, scale}, stream);
+        } else {
+            StorePlainT<false> st{tmp, 1.0f};
+            if (first && inverse)
+                launch_fft_pass<kStridedOnly>(dev, batch, LoadPlainT<true>{src}, st, stream);
+            else
+                launch_fft_pass<kStridedOnly>(dev, batch, LoadPlainT<false>{src}, st, stream);
+        }
     }
 }
 

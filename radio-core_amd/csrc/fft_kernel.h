@@ -188,8 +188,7 @@ struct LineId {
     int64_t o1, o2, i;
 };
 
-// LoadOp:  float2 operator()(const LineId&, int l, int64_t addr)      addr = default input address
-// StoreOp: void   operator()(const LineId&, int k, int64_t addr, float2 v)
+// Runtime-radix fallback for lengths without a specialisation (same functor contracts).
 template <class LoadOp, class StoreOp>
 __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load, StoreOp store) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -224,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             float2 v = make_float2(0.f, 0.f);
             if (w < wvalid) {
                 id.i = i0 + w;
-                v = load.post(id, l, load(id, l, in_base + (int64_t)w * p.in_i + l));
+                v = load.post(id, l, load.fetch(id, l, in_base, (unsigned)(w * p.in_i + l)));
             }
             tile[l * W + (w ^ (l & (W - 1)))] = v;
         }
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             float2 v = make_float2(0.f, 0.f);
             if (w < wvalid) {
                 id.i = i0 + w;
-                v = load.post(id, l, load(id, l, in_base + (int64_t)l * p.in_l + (int64_t)w * p.in_i));
+                v = load.post(id, l, load.fetch(id, l, in_base, (unsigned)(l * p.in_l + w * p.in_i)));
             }
             tile[l * W + w] = v;
         }
@@ -265,294 +264,278 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
         float2 v = tile[row * W + (w ^ (swz & row & (W - 1)))];
         if (p.has_twiddle) v = cmul(v, big_twiddle(d, (tw_base + (unsigned)w * (unsigned)p.tw_i) * (unsigned)k));
         id.i = i0 + w;
-        store(id, k, out_base + (int64_t)k * p.out_k + (int64_t)w * p.out_i, v);
+        store(id, k, out_base, (unsigned)(k * p.out_k + w * p.out_i), v);
     }
 }
 
 // ---- compile-time specialised pass ------------------------------------------------
 //
-// Same algorithm with L and the radices known at compile time: every index division
-// has a constant divisor, all loops unroll, each thread issues all of its global loads
-// before the first use (L/16 independent 8-byte loads per thread in flight), the first
-// DFT stage of a strided pass runs straight from those registers and the last stage
+// Same algorithm with L and the radices known at compile time: every index division has
+// a constant divisor, all loops unroll, each thread issues all of its global loads back to
+// back and unconditionally (L/16 independent 8-byte loads per thread in flight), the
+// first DFT stage of a strided pass runs straight from those registers and the last stage
 // stores straight to memory, so a 3-stage pass makes 2 LDS round trips instead of 4.
 // Thread layout: lane w = tid & 15 is the line inside the tile, rg = tid >> 4 picks the
 // butterfly; the 16 lanes of a row always touch one 128-byte LDS row / global segment.
+// Grid: x = tile along the inner line index, y = outer line index, z = signal in the batch.
+
+// Small DFTs that leave output q' in slot perm<R>(q') (no register shuffling afterwards).
+template <int R>
+__device__ __forceinline__ constexpr int dft_slot(int q) {
+    if (R == 6) return (q % 3) * 2 + q / 3;     // dft6 leaves y[k1 + 3 k2] in v[2 k1 + k2]
+    if (R == 8) return (q % 4) * 2 + q / 4;
+    if (R == 10) return (q % 5) * 2 + q / 5;
+    return q;
+}
+
+__device__ __forceinline__ void dft6p(float2* v) {
+    dft3(v[0], v[2], v[4]);
+    dft3(v[1], v[3], v[5]);
+    v[3] = cmul(v[3], make_float2(0.5f, -0.86602540378443864676f));
+    v[5] = cmul(v[5], make_float2(-0.5f, -0.86602540378443864676f));
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    dft2(v[4], v[5]);
+}
+
+__device__ __forceinline__ void dft8p(float2* v) {
+    constexpr float h = 0.70710678118654752440f;
+    dft4(v[0], v[2], v[4], v[6]);
+    dft4(v[1], v[3], v[5], v[7]);
+    v[3] = cmul(v[3], make_float2(h, -h));
+    v[5] = mul_mi(v[5]);
+    v[7] = cmul(v[7], make_float2(-h, -h));
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    dft2(v[4], v[5]);
+    dft2(v[6], v[7]);
+}
+
+__device__ __forceinline__ void dft10p(float2* v) {
+    dft5(v[0], v[2], v[4], v[6], v[8]);
+    dft5(v[1], v[3], v[5], v[7], v[9]);
+    v[3] = cmul(v[3], make_float2(0.80901699437494742410f, -0.58778525229247312917f));
+    v[5] = cmul(v[5], make_float2(0.30901699437494742410f, -0.95105651629515357212f));
+    v[7] = cmul(v[7], make_float2(-0.30901699437494742410f, -0.95105651629515357212f));
+    v[9] = cmul(v[9], make_float2(-0.80901699437494742410f, -0.58778525229247312917f));
+    dft2(v[0], v[1]);
+    dft2(v[2], v[3]);
+    dft2(v[4], v[5]);
+    dft2(v[6], v[7]);
+    dft2(v[8], v[9]);
+}
 
 template <int R>
-__device__ __forceinline__ void dft_r(float2* v) {
+__device__ __forceinline__ void dft_p(float2* v) {
     if constexpr (R == 2) dft2(v[0], v[1]);
     if constexpr (R == 3) dft3(v[0], v[1], v[2]);
     if constexpr (R == 4) dft4(v[0], v[1], v[2], v[3]);
     if constexpr (R == 5) dft5(v[0], v[1], v[2], v[3], v[4]);
-    if constexpr (R == 6) dft6(v);
-    if constexpr (R == 8) dft8(v);
-    if constexpr (R == 10) dft10(v);
+    if constexpr (R == 6) dft6p(v);
+    if constexpr (R == 8) dft8p(v);
+    if constexpr (R == 10) dft10p(v);
 }
 
-__device__ __forceinline__ int lds_slot(int row, int w, int swz) { return row * W + (w ^ (swz & row & (W - 1))); }
+template <bool SWZ>
+__device__ __forceinline__ int lds_slot(int row, int w) {
+    return SWZ ? row * W + (w ^ (row & (W - 1))) : row * W + w;
+}
 
 // Middle stage: LDS -> LDS.  MT = block length entering the stage.
-template <int L, int R, int MT>
-__device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w, int rg, int swz) {
-    constexpr int m = MT / R, step = L / MT, rows = L / R, nit = (rows + 15) / 16;
+template <int L, int R, int MT, bool SWZ, int RG>
+__device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w, int rg) {
+    constexpr int m = MT / R, step = L / MT, rows = L / R, nit = (rows + RG - 1) / RG;
 #pragma unroll
     for (int it = 0; it < nit; ++it) {
-        const int b = rg + 16 * it;
-        if ((rows % 16 == 0) || b < rows) {
+        const int b = rg + RG * it;
+        if ((rows % RG == 0) || b < rows) {
             const int g = b / m, kp = b - g * m;
             const int base = g * MT + kp;
             float2 v[R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = tile[lds_slot(base + q * m, w, swz)];
-            dft_r<R>(v);
+            for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<SWZ>(base + q * m, w)];
+            dft_p<R>(v);
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[q * kp * step]);
+            for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], tw[q * kp * step]);
 #pragma unroll
-            for (int q = 0; q < R; ++q) tile[lds_slot(base + q * m, w, swz)] = v[q];
+            for (int q = 0; q < R; ++q) tile[lds_slot<SWZ>(base + q * m, w)] = v[dft_slot<R>(q)];
         }
     }
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global
-// loads and stores share that counter on gfx9), which would wait for the prefetched tile at
-// every stage boundary; LDS hand-offs only need lgkmcnt(0) + s_barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Per-tile addressing, decoded once per tile per thread.
-struct TileCtx {
-    LineId id;
-    int64_t i0, in_base, out_base;
-    int wvalid;
-};
-
-__device__ __forceinline__ void decode_tile(const FftPassDev& d, int64_t tile, int64_t tiles_inner,
-                                            int64_t tiles_per_batch, TileCtx& c) {
-    const FftPass& p = d.p;
-    const int64_t batch = tile / tiles_per_batch;
-    int64_t t = tile - batch * tiles_per_batch;
-    const int64_t ti = t % tiles_inner;
-    t /= tiles_inner;
-    c.id.batch = (int)batch;
-    c.id.o2 = t % p.n_o2;
-    c.id.o1 = t / p.n_o2;
-    c.id.i = 0;
-    c.i0 = ti * W;
-    c.wvalid = (int)((p.n_inner - c.i0) < W ? (p.n_inner - c.i0) : W);
-    c.in_base = batch * d.in_batch + c.id.o1 * p.in_o1 + c.id.o2 * p.in_o2 + c.i0 * p.in_i;
-    c.out_base = batch * d.out_batch + c.id.o1 * p.out_o1 + c.id.o2 * p.out_o2 + c.i0 * p.out_i;
-}
-
-// Persistent workgroups: each loops over tiles (grid-stride) and issues the global loads of
-// its NEXT tile right after the first DFT stage has consumed the registers of the current
-// one, so HBM latency hides behind the remaining stages instead of being paid per tile
-// (with 65 KiB of LDS only two workgroups fit a CU: there is no other latency hiding).
-// PERSIST = false: one tile per workgroup, no loop (short lengths: 8 workgroups per CU hide
-// the latency by themselves).
-template <int L, int R0, int R1, int R2, int R3, bool ROWS, bool PERSIST, class LoadOp, class StoreOp>
-__global__ __launch_bounds__(kThreads) void k_fft_pass_t(FftPassDev d, LoadOp load, StoreOp store,
-                                                         int64_t total_tiles, int64_t tiles_per_batch) {
+// LoadOp contract:  fetch(id, l, tile_base, off) returns element tile_base + off of the input
+//                   (tile_base is workgroup-uniform, off a 32-bit per-lane offset) and does NO
+//                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
+// StoreOp contract: operator()(id, k, tile_base, off, v).
+template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
+__global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, StoreOp store) {
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
     constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;   // last radix
     constexpr int m0 = L / R0;
-    constexpr int nit0 = (m0 + 15) / 16;                       // first-stage butterflies per thread
-    constexpr int nld = ROWS ? (L * W + kThreads - 1) / kThreads : nit0 * R0;
-    constexpr int swz = ROWS ? (W - 1) : 0;
+    constexpr int RG = T / W;                                  // butterfly rows handled per sweep
+    constexpr int nit0 = (m0 + RG - 1) / RG;                   // first-stage butterflies per thread
+    constexpr int nld = ROWS ? (L * W + T - 1) / T : nit0 * R0;
     __shared__ __attribute__((aligned(16))) float2 tile[L * W];
     __shared__ __attribute__((aligned(16))) float2 tw[L];
     const FftPass& p = d.p;
     const int tid = threadIdx.x;
-    int w = tid & (W - 1), rg = tid >> 4;
-    unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
-    const int64_t tiles_inner = (p.n_inner + W - 1) / W;
+    const int w = tid & (W - 1), rg = tid >> 4;
 
-    // XCD-aware order: workgroup b runs on XCD b % 8 (observed, speed only); give each XCD a
-    // contiguous run of tiles so neighbouring 128-byte segments meet in one L2.
-    const int64_t G = gridDim.x;
-    const int64_t vb = (G % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+    LineId id;
+    id.batch = blockIdx.z;
+    const unsigned o = blockIdx.y, n_o2 = (unsigned)p.n_o2;
+    id.o1 = n_o2 == 1 ? o : o / n_o2;
+    id.o2 = n_o2 == 1 ? 0 : o - (unsigned)id.o1 * n_o2;
+    const int i0 = blockIdx.x * W;
+    const int left = (int)p.n_inner - i0;
+    const int wvalid = left < W ? left : W;
+    const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + (int64_t)i0 * p.in_i;
+    const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0;
+    const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
 
+    // ---- global loads: all issued before anything waits -----------------------------------
     float2 v[nld];
-    // Loads are issued unconditionally from clamped (always valid) addresses and masked
-    // afterwards: a load under `if` costs a branch plus an immediate s_waitcnt vmcnt(0),
-    // i.e. one serialized HBM round trip per element.
-    auto issue_loads = [&](TileCtx& c) {
-        if constexpr (ROWS) {
+    if constexpr (ROWS) {
 #pragma unroll
-            for (int it = 0; it < nld; ++it) {
-                int e = tid + kThreads * it;
-                if ((L * W) % kThreads != 0) e = e < L * W ? e : 0;
-                const int wl = e / L, l = e - wl * L;
-                const int wc = wl < c.wvalid ? wl : 0;
-                c.id.i = c.i0 + wc;
-                v[it] = load(c.id, l, c.in_base + (int64_t)((unsigned)wc * in_i + (unsigned)l));
-            }
-        } else {
-            const int wc = w < c.wvalid ? w : 0;
-            c.id.i = c.i0 + wc;
+        for (int it = 0; it < nld; ++it) {
+            int e = tid + T * it;
+            if ((L * W) % T != 0) e = e < L * W ? e : 0;
+            const int wl = e / L, l = e - wl * L;
+            const int wc = wl < wvalid ? wl : 0;     // clamped: always a valid line
+            id.i = i0 + wc;
+            v[it] = load.fetch(id, l, in_base, (unsigned)wc * in_i + (unsigned)l);
+        }
+    } else {
+        const int wc = w < wvalid ? w : 0;
+        id.i = i0 + wc;
 #pragma unroll
-            for (int it = 0; it < nit0; ++it) {
-                int b = rg + 16 * it;
-                if (m0 % 16 != 0) b = b < m0 ? b : 0;
+        for (int it = 0; it < nit0; ++it) {
+            int b = rg + RG * it;
+            if (m0 % RG != 0) b = b < m0 ? b : 0;
 #pragma unroll
-                for (int q = 0; q < R0; ++q) {
-                    const int l = b + q * m0;
-                    v[it * R0 + q] = load(c.id, l, c.in_base + (int64_t)((unsigned)l * in_l + (unsigned)wc));
-                }
+            for (int q = 0; q < R0; ++q) {
+                const int l = b + q * m0;
+                v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
             }
         }
-    };
-    // At consume time: the functor's arithmetic (LoadOp::post -- kept out of issue_loads so the
-    // prefetch has no consumer until here), then zero the lanes of a partial tile (their
-    // clamped loads fetched line 0).
-    auto mask_loads = [&](TileCtx& c) {
-        if constexpr (ROWS) {
-#pragma unroll
-            for (int it = 0; it < nld; ++it) {
-                const int e = tid + kThreads * it;
-                const int wl = e / L, l = e - wl * L;
-                c.id.i = c.i0 + wl;
-                v[it] = load.post(c.id, l, v[it]);
-                if (wl >= c.wvalid) v[it] = make_float2(0.f, 0.f);
-            }
-        } else {
-            c.id.i = c.i0 + w;
-#pragma unroll
-            for (int it = 0; it < nit0; ++it) {
-#pragma unroll
-                for (int q = 0; q < R0; ++q) {
-                    v[it * R0 + q] = load.post(c.id, rg + 16 * it + q * m0, v[it * R0 + q]);
-                    if (w >= c.wvalid) v[it * R0 + q] = make_float2(0.f, 0.f);
-                }
-            }
-        }
-    };
-
-    TileCtx cur;
-    int64_t tile_id = vb;
-    if (tile_id < total_tiles) {
-        decode_tile(d, tile_id, tiles_inner, tiles_per_batch, cur);
-        issue_loads(cur);
     }
-    for (int e = tid; e < L; e += kThreads) tw[e] = d.stage_tw[e];
+    for (int e = tid; e < L; e += T) tw[e] = d.stage_tw[e];
+
+    // ---- first stage ---------------------------------------------------------------------
+    if constexpr (ROWS) {
+#pragma unroll
+        for (int it = 0; it < nld; ++it) {
+            const int e = tid + T * it;
+            const int wl = e / L, l = e - wl * L;
+            id.i = i0 + wl;
+            float2 x = load.post(id, l, v[it]);
+            if (wl >= wvalid) x = make_float2(0.f, 0.f);
+            if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
+        }
+        __syncthreads();
+        stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+    } else {
+        __syncthreads();   // tw[] complete
+        id.i = i0 + w;
+#pragma unroll
+        for (int it = 0; it < nit0; ++it) {
+            const int b = rg + RG * it;
+            if ((m0 % RG == 0) || b < m0) {
+                float2* x = &v[it * R0];
+#pragma unroll
+                for (int q = 0; q < R0; ++q) {
+                    x[q] = load.post(id, b + q * m0, x[q]);
+                    if (w >= wvalid) x[q] = make_float2(0.f, 0.f);
+                }
+                dft_p<R0>(x);
+#pragma unroll
+                for (int q = 1; q < R0; ++q) x[dft_slot<R0>(q)] = cmul(x[dft_slot<R0>(q)], tw[q * b]);
+#pragma unroll
+                for (int q = 0; q < R0; ++q) tile[lds_slot<false>(b + q * m0, w)] = x[dft_slot<R0>(q)];
+            }
+        }
+    }
     __syncthreads();
+    if constexpr (S >= 3) {
+        stage_lds<L, R1, L / R0, ROWS, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+    if constexpr (S >= 4) {
+        stage_lds<L, R2, L / (R0 * R1), ROWS, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
 
-    while (tile_id < total_tiles) {
-        if constexpr (PERSIST) {
-            // Keep per-thread offsets (l * in_l + w, LDS slots, k * out_k) out of registers across
-            // iterations: hoisted, they cost ~150 VGPRs and halve the occupancy.
-            asm volatile("" : "+v"(w), "+v"(rg));
-            asm volatile("" : "+s"(in_l), "+s"(in_i), "+s"(out_k));
-        }
-        // ---- first stage -------------------------------------------------------
-        mask_loads(cur);
-        if constexpr (ROWS) {
+    // ---- last stage (block length RL, no stage twiddle): LDS -> registers -> memory ---------
+    // Block g holds outputs k = kb(g) + (L / RL) q': g's digits are q_1 .. q_{S-1} with weights
+    // L/(r_1 RL), L/(r_1 r_2 RL), ...; kb = q_1 + r_1 q_2 + r_1 r_2 q_3.
+    // Inter-pass twiddle W_n^(f k), f = this lane's line factor: W_n^(f kb) once per butterfly,
+    // then successive powers of D = W_n^(f L / RL) (RL - 1 <= 9 multiplications).
+    constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
+    const unsigned f = (unsigned)(id.o1 * p.tw_o1 + id.o2 * p.tw_o2 + (int64_t)(i0 + w) * p.tw_i);
+    float2 D = make_float2(1.f, 0.f);
+    if constexpr (!ROWS) D = big_twiddle(d, f * (unsigned)(L / RL));
+    id.i = i0 + w;
+    const bool lane_ok = w < wvalid;
 #pragma unroll
-            for (int it = 0; it < nld; ++it) {
-                const int e = tid + kThreads * it;
-                const int wl = e / L, l = e - wl * L;
-                if ((L * W) % kThreads == 0 || e < L * W) tile[lds_slot(l, wl, swz)] = v[it];
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            float2 x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<ROWS>(g * RL + q, w)];
+            dft_p<RL>(x);
+            int kb;
+            if constexpr (S == 2) {
+                kb = g;
+            } else if constexpr (S == 3) {
+                constexpr int w1 = L / (R0 * RL);
+                const int q1 = g / w1, q2 = g - q1 * w1;
+                kb = q1 + R0 * q2;
+            } else {
+                constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
+                const int q1 = g / w1, r1 = g - q1 * w1;
+                const int q2 = r1 / w2, q3 = r1 - q2 * w2;
+                kb = q1 + R0 * (q2 + R1 * q3);
             }
-            lds_barrier();
-        } else {
+            float2 Tw = make_float2(1.f, 0.f);
+            if constexpr (!ROWS) Tw = big_twiddle(d, f * (unsigned)kb);
+            if (lane_ok) {
 #pragma unroll
-            for (int it = 0; it < nit0; ++it) {
-                const int b = rg + 16 * it;
-                if ((m0 % 16 == 0) || b < m0) {
-                    dft_r<R0>(&v[it * R0]);
-#pragma unroll
-                    for (int q = 1; q < R0; ++q) v[it * R0 + q] = cmul(v[it * R0 + q], tw[q * b]);
-#pragma unroll
-                    for (int q = 0; q < R0; ++q) tile[lds_slot(b + q * m0, w, swz)] = v[it * R0 + q];
-                }
-            }
-            lds_barrier();
-        }
-        // ---- prefetch the next tile (registers are free again) -------------------
-        const int64_t next_id = tile_id + G;
-        TileCtx nxt = cur;
-        if (PERSIST && next_id < total_tiles) {
-            decode_tile(d, next_id, tiles_inner, tiles_per_batch, nxt);
-            issue_loads(nxt);
-        }
-        if constexpr (ROWS) {
-            stage_lds<L, R0, L>(tile, tw, w, rg, swz);
-            lds_barrier();
-        }
-        if constexpr (S >= 3) {
-            stage_lds<L, R1, L / R0>(tile, tw, w, rg, swz);
-            lds_barrier();
-        }
-        if constexpr (S >= 4) {
-            stage_lds<L, R2, L / (R0 * R1)>(tile, tw, w, rg, swz);
-            lds_barrier();
-        }
-
-        // ---- last stage (block length RL, no stage twiddle): LDS -> registers -> memory.
-        // Block g holds outputs k = kb(g) + (L / RL) q': g's digits are q_1 .. q_{S-1} with
-        // weights L/(r_1 RL), L/(r_1 r_2 RL), ...; kb = q_1 + r_1 q_2 + r_1 r_2 q_3.
-        constexpr int rowsL = L / RL, nitL = (rowsL + 15) / 16;
-        const unsigned f = (unsigned)(cur.id.o1 * p.tw_o1 + cur.id.o2 * p.tw_o2 + (cur.i0 + w) * p.tw_i);
-        cur.id.i = cur.i0 + w;
-        const bool lane_ok = w < cur.wvalid;
-#pragma unroll
-        for (int it = 0; it < nitL; ++it) {
-            const int g = rg + 16 * it;
-            if ((rowsL % 16 == 0) || g < rowsL) {
-                float2 o[RL];
-#pragma unroll
-                for (int q = 0; q < RL; ++q) o[q] = tile[lds_slot(g * RL + q, w, swz)];
-                dft_r<RL>(o);
-                int kb;
-                if constexpr (S == 2) {
-                    kb = g;
-                } else if constexpr (S == 3) {
-                    constexpr int w1 = L / (R0 * RL);
-                    const int q1 = g / w1, q2 = g - q1 * w1;
-                    kb = q1 + R0 * q2;
-                } else {
-                    constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
-                    const int q1 = g / w1, r1 = g - q1 * w1;
-                    const int q2 = r1 / w2, q3 = r1 - q2 * w2;
-                    kb = q1 + R0 * (q2 + R1 * q3);
-                }
-                if (lane_ok) {
-#pragma unroll
-                    for (int q = 0; q < RL; ++q) {
-                        const int k = kb + (L / RL) * q;
-                        float2 x = o[q];
-                        if constexpr (!ROWS) x = cmul(x, big_twiddle(d, f * (unsigned)k));   // ROWS = last pass
-                        store(cur.id, k, cur.out_base + (int64_t)((unsigned)k * out_k + (unsigned)w), x);
+                for (int q = 0; q < RL; ++q) {
+                    const int k = kb + (L / RL) * q;
+                    float2 y = x[dft_slot<RL>(q)];
+                    if constexpr (!ROWS) {
+                        y = cmul(y, Tw);
+                        Tw = cmul(Tw, D);
                     }
+                    store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
                 }
             }
         }
-        if constexpr (!PERSIST) break;
-        lds_barrier();   // all reads of this tile are done before the next one lands in LDS
-        cur = nxt;
-        tile_id = next_id;
     }
 }
 
 // ---- plain functors ------------------------------------------------------------
+// SWAP = exchange re/im: the inverse transform by the swap identity ifft(x) = swap(fft(swap(x))).
 
-// LoadOp contract: operator() only fetches (no arithmetic on the result: the specialised
-// kernel issues it one tile ahead); post() runs when the tile is consumed.
-struct LoadPlain {
+template <bool SWAP>
+struct LoadPlainT {
     const float2* in;
-    int swap;   // 1: exchange re/im (inverse transform by the swap identity)
-    __device__ __forceinline__ float2 operator()(const LineId&, int, int64_t a) const { return in[a]; }
+    __device__ __forceinline__ float2 fetch(const LineId&, int, int64_t base, unsigned off) const {
+        return (in + base)[off];
+    }
     __device__ __forceinline__ float2 post(const LineId&, int, float2 v) const {
-        return swap ? make_float2(v.y, v.x) : v;
+        return SWAP ? make_float2(v.y, v.x) : v;
     }
 };
 
-struct StorePlain {
+template <bool SWAP>
+struct StorePlainT {
     float2* out;
-    int swap;
     float scale;
-    __device__ __forceinline__ void operator()(const LineId&, int, int64_t a, float2 v) const {
-        out[a] = swap ? make_float2(v.y * scale, v.x * scale) : make_float2(v.x * scale, v.y * scale);
+    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
+        (out + base)[off] = SWAP ? make_float2(v.y * scale, v.x * scale) : make_float2(v.x * scale, v.y * scale);
     }
 };
 
@@ -575,56 +558,39 @@ struct StorePlain {
     X(500, 10, 10, 5, 1)         \
     X(512, 8, 8, 8, 1)
 
-inline bool getenv_flag(const char* name) {
-    const char* e = std::getenv(name);
-    return e && e[0] == '1';
-}
+// Threads per tile.  Long tiles are LDS-limited to two workgroups per CU; 512 threads keep
+// 16 waves per CU in flight there (build with -DRCFM_FFT_LONG_THREADS=256 to compare).
+#ifndef RCFM_FFT_LONG_THREADS
+#define RCFM_FFT_LONG_THREADS 512
+#endif
+constexpr int tile_threads(int L) { return L >= 320 ? RCFM_FFT_LONG_THREADS : 256; }
 
-template <int LEN, int A, int B, int C, int D, class LoadOp, class StoreOp>
-inline void launch_variant(bool rows, bool persist, dim3 grid, hipStream_t s, const FftPassDev& d,
-                           const LoadOp& ld, const StoreOp& st, int64_t total, int64_t tpb) {
-    // short lengths never loop; long ones only exist in the persistent form
-    constexpr bool kLong = LEN >= 200;
-    if (rows) {
-        if (kLong && persist)
-            hipLaunchKernelGGL((k_fft_pass_t<LEN, A, B, C, D, true, kLong, LoadOp, StoreOp>), grid, dim3(kThreads),
-                               0, s, d, ld, st, total, tpb);
-        else
-            hipLaunchKernelGGL((k_fft_pass_t<LEN, A, B, C, D, true, false, LoadOp, StoreOp>), grid,
-                               dim3(kThreads), 0, s, d, ld, st, total, tpb);
-    } else {
-        if (kLong && persist)
-            hipLaunchKernelGGL((k_fft_pass_t<LEN, A, B, C, D, false, kLong, LoadOp, StoreOp>), grid,
-                               dim3(kThreads), 0, s, d, ld, st, total, tpb);
-        else
-            hipLaunchKernelGGL((k_fft_pass_t<LEN, A, B, C, D, false, false, LoadOp, StoreOp>), grid,
-                               dim3(kThreads), 0, s, d, ld, st, total, tpb);
-    }
-}
+// Which pass kinds a functor pair is ever used with (prunes template instantiations).
+enum PassKinds : int { kAnyPass = 0, kStridedOnly = 1, kRowsOnly = 2 };
 
-template <class LoadOp, class StoreOp>
+template <int KIND = kAnyPass, class LoadOp, class StoreOp>
 inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, const StoreOp& st, hipStream_t s) {
     bool done = false;
-    const bool strided_ok = d.p.load_along_l || (d.p.in_i == 1);
-    const bool store_ok = (d.p.out_i == 1) && ((d.p.has_twiddle != 0) == (d.p.load_along_l == 0));
-    if (strided_ok && store_ok && !getenv_generic_fft()) {
-        const int64_t tiles_per_batch = d.p.n_o1 * d.p.n_o2 * ((d.p.n_inner + W - 1) / W);
-        const int64_t total = tiles_per_batch * batch;
-        // persistent grid: as many workgroups as fit the chip at once (LDS-limited), multiple of 8
-        const size_t lds = (size_t)d.p.L * (W + 1) * sizeof(float2);
-        int per_cu = (int)(160 * 1024 / lds);
-        per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-        int64_t g = (int64_t)FftEngine::compute_units() * per_cu;
-        if (g > total) g = total;
-        if (g >= 8) g -= g % 8;
-        const bool persist = d.p.L >= 200 && !getenv_flag("RCFM_FFT_NOPERSIST");
-        const dim3 grid((unsigned)(persist ? g : total), 1, 1);
+    const bool rows = d.p.load_along_l != 0;
+    RC_REQUIRE(!(KIND == kStridedOnly && rows) && !(KIND == kRowsOnly && !rows), RCFM_ERR_RUNTIME,
+               "FFT functor used with the wrong pass kind");
+    const bool shape_ok = (rows || d.p.in_i == 1) && d.p.out_i == 1 && ((d.p.has_twiddle != 0) == !rows) &&
+                          d.p.n_o1 * d.p.n_o2 <= 65535 && batch <= 65535;
+    if (shape_ok && !getenv_generic_fft()) {
+        const dim3 grid((unsigned)((d.p.n_inner + W - 1) / W), (unsigned)(d.p.n_o1 * d.p.n_o2), (unsigned)batch);
         switch (d.p.L) {
-#define RCFM_CASE(LEN, A, B, C, D)                                                                              \
-    case LEN:                                                                                                   \
-        launch_variant<LEN, A, B, C, D>(d.p.load_along_l != 0, persist, grid, s, d, ld, st, total,               \
-                                        tiles_per_batch);                                                       \
-        done = true;                                                                                            \
+#define RCFM_CASE(LEN, A, B, C, D)                                                                            \
+    case LEN:                                                                                                 \
+        if (rows) {                                                                                           \
+            if constexpr (KIND != kStridedOnly)                                                               \
+                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, true, tile_threads(LEN), LoadOp, StoreOp>), grid, \
+                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
+        } else {                                                                                              \
+            if constexpr (KIND != kRowsOnly)                                                                  \
+                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, false, tile_threads(LEN), LoadOp, StoreOp>), grid, \
+                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
+        }                                                                                                     \
+        done = true;                                                                                          \
         break;
             RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE

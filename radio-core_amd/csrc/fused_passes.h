@@ -1,0 +1,42 @@
+// FFT passes with the radio path's element-wise stages riding on their loads / stores
+// (fused_passes.hip).  Each function is one complete transform of `count` signals.
+#pragma once
+
+#include "fft_engine.h"
+
+namespace rcfm {
+
+// Tuner.run (tuner.py:159-161) for `count` channels of bandwidth B = e.desc().n:
+// bin gather from the wideband spectrum X (circular roll, fftshifted periodic window
+// a0 - (1-a0) cos(2 pi i / N), truncation, Nyquist merge) is the load of the first pass of
+// the inverse FFT; out = ifft(Y) * B / N.
+struct TunerGather {
+    const float2* X;
+    int64_t N;
+    const int64_t* roll;   // device, one entry per channel of the range, already in [0, N)
+    double a0;
+    int nyq, nneg, nyq_mode;
+};
+void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
+                      hipStream_t s);
+
+// Forward FFT of real signals x [count][n] -> full complex spectrum U [count][n].
+// keep >= 0: only bins |k| <= keep are written (the rest of U is left untouched).
+void fused_real_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
+                    hipStream_t s);
+
+// pll.py:34 + wbfm.py:83,86-87: z = ifft(h U) (scipy.signal.hilbert's one-sided mask as the
+// load of the first pass), then s2 = Im(z^2)/|z^2|, lmr = s2 m 1.0175 and the packed stereo
+// signal u = (m + lmr) + j (m - lmr) as the store of the last pass.  U and u may alias.
+void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
+                            int count, hipStream_t s);
+
+// Forward FFT whose last pass stores only the bins |k| <= keep (decimation to A needs no more).
+void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,
+                      hipStream_t s);
+
+// Inverse FFT of a Hermitian spectrum Y [count][n] whose real result goes to y [count][n] floats.
+void fused_ifft_real_out(const FftEngine& e, const float2* Y, float* y, float2* tmp, int count, float scale,
+                         hipStream_t s);
+
+}  // namespace rcfm

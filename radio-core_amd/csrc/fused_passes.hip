@@ -1,0 +1,226 @@
+#include "fused_passes.h"
+
+#include "fft_kernel.h"
+#include "kernels.h"
+
+namespace rcfm {
+
+using fftk::LineId;
+using fftk::kAnyPass;
+using fftk::kRowsOnly;
+using fftk::kStridedOnly;
+
+namespace {
+
+// ---- functors -------------------------------------------------------------------------
+// LoadOp::operator() fetches only; LoadOp::post does the arithmetic when the tile is consumed.
+
+// First pass of Tuner.run's inverse FFT: element k of the channel spectrum comes from
+// bin (src - roll) mod N of the wideband spectrum, src = k (k < nyq) or N - (B - k).
+struct LoadTunerGather {
+    const float2* X;
+    const int64_t* roll;
+    int64_t N;
+    double inv_n;
+    float a0;
+    int B, nyq, nneg, nyq_mode;
+    int64_t line_stride;   // in_l of the pass: k = l * line_stride + i
+
+    __device__ __forceinline__ int64_t source_bin(int k) const {
+        if (k < nyq) return k;
+        const int j = B - k;
+        if (j <= nneg) return N - j;
+        if (nyq_mode == NYQ_UP && j == nyq - 1) return nyq - 1;   // Y[-N/2] = Y[+N/2] / 2
+        return -1;
+    }
+    __device__ __forceinline__ int64_t rolled(int64_t src, int64_t r) const {
+        int64_t i = src - r;
+        return i < 0 ? i + N : i;
+    }
+    // fftshift(get_window(...))[src] = a0 - (1 - a0) cos(2 pi ((src - N//2) mod N) / N)
+    __device__ __forceinline__ float window(int64_t src) const {
+        int64_t i = src - N / 2;
+        if (i < 0) i += N;
+        const float frac = (float)((double)i * inv_n);
+        return a0 - (1.f - a0) * cospif(2.f * frac);
+    }
+    __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
+        const int64_t src = source_bin((int)(base + off));   // in_batch = 0: base + off = bin inside the channel
+        return X[rolled(src < 0 ? 0 : src, roll[id.batch])];
+    }
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 v) const {
+        const int k = (int)(l * line_stride + id.i);
+        const int64_t src = source_bin(k);
+        float w = src < 0 ? 0.f : window(src);
+        const int half = nyq - 1;
+        if (k == half && nyq_mode == NYQ_UP) w *= 0.5f;
+        if (k != half && (B - k) == half && nyq_mode == NYQ_UP) w *= 0.5f;
+        float2 y = make_float2(v.x * w, v.y * w);
+        if (k == half && nyq_mode == NYQ_DOWN) {   // Y[+N/2] += X[-N/2]: one element per channel
+            const int64_t s2 = N - half;
+            const float2 x2 = X[rolled(s2, roll[id.batch])];
+            const float w2 = window(s2);
+            y.x += x2.x * w2;
+            y.y += x2.y * w2;
+        }
+        return make_float2(y.y, y.x);   // inverse transform by the swap identity
+    }
+};
+
+struct LoadRealAsComplex {
+    const float* x;
+    __device__ __forceinline__ float2 fetch(const LineId&, int, int64_t base, unsigned off) const {
+        return make_float2((x + base)[off], 0.f);
+    }
+    __device__ __forceinline__ float2 post(const LineId&, int, float2 v) const { return v; }
+};
+
+// scipy.signal.hilbert's mask on the full spectrum U: h = {1, 2, ..., 2, (1), 0, ...}.
+struct LoadHilbertMask {
+    const float2* U;
+    int n;
+    int64_t line_stride;
+    __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
+        // bins above n/2 are zeroed: read the channel's bin 0 again instead (cache hit, no HBM)
+        const int64_t cbase = (int64_t)id.batch * n;
+        const int64_t a = base + off;
+        return U[(a - cbase) <= n / 2 ? a : cbase];
+    }
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 v) const {
+        const int k = (int)(l * line_stride + id.i);
+        float h = 0.f;
+        if (k == 0) h = 1.f;
+        else if (k < (n + 1) / 2) h = 2.f;
+        else if ((n & 1) == 0 && k == n / 2) h = 1.f;
+        return make_float2(v.y * h, v.x * h);   // swapped: inverse transform
+    }
+};
+
+// Last pass of the analytic-signal IFFT: z (still swapped) -> stereo mix -> packed u.
+struct StoreStereoMix {
+    const float* m;
+    float2* u;
+    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
+        const int64_t a = base + off;
+        // z = (v.y, v.x); Im(z^2)/|z^2| = 2 ab / (a^2 + b^2), pre-scaled against underflow;
+        // z == 0 gives NaN like pll.py:57-58
+        const float s = fmaxf(fabsf(v.x), fabsf(v.y));
+        const float za = v.y / s, zb = v.x / s;
+        const float s2 = (2.f * za * zb) / (za * za + zb * zb);
+        const float mm = m[a];
+        const float lmr = (s2 * mm) * 1.0175f;
+        u[a] = make_float2(mm + lmr, mm - lmr);
+    }
+};
+
+struct StorePruned {
+    float2* out;
+    int n, keep;
+    __device__ __forceinline__ void operator()(const LineId& id, int, int64_t base, unsigned off, float2 v) const {
+        const int k = (int)(base + off - (int64_t)id.batch * n);
+        if (keep < 0 || k <= keep || k >= n - keep) (out + base)[off] = v;
+    }
+};
+
+struct StoreRealPart {
+    float* y;
+    float scale;
+    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
+        (y + base)[off] = v.y * scale;   // swap identity: the real part of the inverse transform is v.y
+    }
+};
+
+// Runs passes [first, last] of a plan with plain functors between tmp buffers.
+void middle_passes(const FftEngine& e, int from, int to, float2* tmp, int count, hipStream_t s) {
+    const int64_t n = e.desc().n;
+    for (int t = from; t <= to; ++t) {
+        fftk::LoadPlainT<false> ld{tmp};
+        fftk::StorePlainT<false> st{tmp, 1.0f};
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(t, n, n), count, ld, st, s);
+    }
+}
+
+}  // namespace
+
+void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
+                      hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t B = e.desc().n;
+    const int np = e.npass();
+    LoadTunerGather ld;
+    ld.X = g.X;
+    ld.roll = g.roll;
+    ld.N = g.N;
+    ld.inv_n = 1.0 / (double)g.N;
+    ld.a0 = (float)g.a0;
+    ld.B = (int)B;
+    ld.nyq = g.nyq;
+    ld.nneg = g.nneg;
+    ld.nyq_mode = g.nyq_mode;
+    ld.line_stride = e.desc().pass[0].in_l;
+    // in_batch = 0: the load functor addresses X itself; `a` is the bin index inside the channel
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, B), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    fftk::StorePlainT<true> stl{out, (float)(1.0 / (double)g.N)};   // ifft (1/B) * (B/N)
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, B, B), count, ldl, stl, s);
+}
+
+void fused_real_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
+                    hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    LoadRealAsComplex ld{x};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    StorePruned stl{U, (int)n, keep};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+}
+
+void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
+                            int count, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    LoadHilbertMask ld{U, (int)n, e.desc().pass[0].in_l};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    StoreStereoMix stl{m, u};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+}
+
+void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,
+                      hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    fftk::LoadPlainT<false> ld{in};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    StorePruned stl{out, (int)n, keep};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+}
+
+void fused_ifft_real_out(const FftEngine& e, const float2* Y, float* y, float2* tmp, int count, float scale,
+                         hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    fftk::LoadPlainT<true> ld{Y};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    StoreRealPart stl{y, scale};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+}
+
+}  // namespace rcfm

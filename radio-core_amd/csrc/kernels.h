@@ -25,6 +25,11 @@ void launch_spectrum_c2c(const float2* X, int64_t x_stride, int64_t n, const int
 void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
                          int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream);
 
+// Same resampling rule, but from the FULL complex spectrum X [batch][n] of a real signal to
+// the full Hermitian spectrum Y [batch][m] (feeds a complex inverse FFT whose real part is y).
+void launch_spectrum_real_full(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
+                               int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream);
+
 // scipy.signal.hilbert's mask (pll.py:34): P [batch][n/2+1] half spectrum of the real
 // input -> Z [batch][n] one-sided spectrum {1, 2, ..., 2, 1, 0, ...} * scale.
 void launch_hilbert_mask(const float2* P, float2* Z, int64_t n, int batch, float scale,

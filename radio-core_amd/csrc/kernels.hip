@@ -81,6 +81,25 @@ __global__ __launch_bounds__(kThreads) void k_spectrum_r2c(const float2* __restr
     Y[(int64_t)c * mh + k] = cscale(y, scale);
 }
 
+__global__ __launch_bounds__(kThreads) void k_spectrum_real_full(const float2* __restrict__ X, int64_t n,
+                                                                 float2* __restrict__ Y, int64_t m,
+                                                                 const float* __restrict__ wr, int nyq, int nmin,
+                                                                 float nyq_factor, float scale) {
+    const int c = blockIdx.y;
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= m) return;
+    const bool mirrored = k > m / 2;
+    const int64_t kk = mirrored ? m - k : k;
+    float2 y = make_float2(0.f, 0.f);
+    if (kk < nyq) {
+        y = cscale(X[(int64_t)c * n + kk], wr[kk] * scale);
+        if ((nmin & 1) == 0 && kk == nmin / 2) y = cscale(y, nyq_factor);
+        if (kk == 0 || ((m & 1) == 0 && kk == m / 2)) y.y = 0.f;
+    }
+    if (mirrored) y.y = -y.y;
+    Y[(int64_t)c * m + k] = y;
+}
+
 __global__ __launch_bounds__(kThreads) void k_hilbert_mask(const float2* __restrict__ P,
                                                            float2* __restrict__ Z, int64_t n, float scale) {
     const int c = blockIdx.y;
@@ -372,6 +391,14 @@ void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int b
     if (batch <= 0) return;
     hipLaunchKernelGGL(k_spectrum_r2c, grid2(m / 2 + 1, kThreads, batch), dim3(kThreads), 0, stream, X, n, Y,
                        m, wr, nyq, nmin, nyq_factor, scale);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_spectrum_real_full(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
+                               int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(k_spectrum_real_full, grid2(m, kThreads, batch), dim3(kThreads), 0, stream, X, n, Y, m,
+                       wr, nyq, nmin, nyq_factor, scale);
     RC_LAUNCH_CHECK();
 }
 
