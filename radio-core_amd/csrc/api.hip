@@ -316,12 +316,13 @@ struct rcfm_demod_s {
     float taps_h[51];
     float zi_h[50];
     float pilot_h[41];
+    float pilot_g_h[41];   // zero-phase kernel g = b (*) reverse(b), centre first
     DeviceBuffer taps, pilot_g, state;
     float side_tap = 0.23f;
     ResampleGeom geom;   // B -> A, real, Hamming
     PlanCache r2c_B, c2c_inv_B, c2c_fwd_B, c2c_inv_A, c2r_A;
     std::unique_ptr<FftEngine> eng_B, eng_A;   // both set: the engine path with fused passes
-    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA;
+    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2;
     int tiles = 0;
 
     void alloc() {
@@ -347,6 +348,7 @@ struct rcfm_demod_s {
             eng_A = std::make_unique<FftEngine>(A);
             buf_T.reset(c * B * sizeof(float2));
             buf_TA.reset(c * A * sizeof(float2));
+            if (kind == RCFM_WBFM) buf_U2.reset(((c + 1) / 2) * B * sizeof(float2));
             if (kind != RCFM_WBFM) {
                 buf_Z.reset(c * B * sizeof(float2));   // full spectrum of the discriminator output
                 buf_V.reset(c * A * sizeof(float2));   // Hermitian audio spectrum
@@ -381,18 +383,22 @@ struct rcfm_demod_s {
             // wbfm.py:77-80  FM(B->B) and the pilot band-pass
             {
                 StageTimer tm(ST_PILOT, s);
-                launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
+                if (B % 4 == 0)
+                    launch_pilot_stage_h40(iq, m, p, B, cnt, pilot_g_h, side_tap, s);
+                else
+                    launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
             }
             if (eng_B) {
                 float2* T = buf_T.as<float2>();
                 float2* TA = buf_TA.as<float2>();
-                {   // wbfm.py:80 / pll.py:34: spectrum of the pilot band
+                float2* U2 = buf_U2.as<float2>();
+                {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
                     StageTimer tm(ST_FFT_REAL_B, s);
-                    fused_real_fft(*eng_B, p, Z, T, cnt, -1, s);
+                    fused_real_pair_fft(*eng_B, p, U2, T, cnt, s);
                 }
                 {   // one-sided mask -> inverse FFT -> 38 kHz carrier, L-R, stereo matrix (wbfm.py:83,86-87)
                     StageTimer tm(ST_IFFT_B, s);
-                    fused_hilbert_ifft_mix(*eng_B, Z, m, Z, T, cnt, s);
+                    fused_hilbert_pair_ifft_mix(*eng_B, U2, m, Z, T, cnt, s);
                 }
                 {   // both stereo legs in one complex FFT; only |k| <= A/2 survives the decimation
                     StageTimer tm(ST_FFT_B, s);
@@ -707,6 +713,7 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
             auto h = firwin_bandpass(41, lo, hi);
             for (int i = 0; i < 41; ++i) d->pilot_h[i] = (float)h[i];
             auto g = zero_phase_kernel(d->pilot_h, 41);
+            std::memcpy(d->pilot_g_h, g.data(), sizeof(d->pilot_g_h));
             d->pilot_g.upload(g.data(), g.size() * sizeof(float));
             d->side_tap = (B % 2) ? (float)(0.23 * std::cos(kPi / (double)B)) : 0.23f;
         }

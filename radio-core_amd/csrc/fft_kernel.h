@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "fft_engine.h"
 
@@ -188,6 +189,20 @@ struct LineId {
     int64_t o1, o2, i;
 };
 
+// A LoadOp may need two input values per point (kFetches = 2: fetch + fetch2, post(id, l, a, b)).
+template <class T, class = void>
+struct fetch_count { static constexpr int value = 1; };
+template <class T>
+struct fetch_count<T, std::void_t<decltype(T::kFetches)>> { static constexpr int value = T::kFetches; };
+
+template <class LoadOp>
+__device__ __forceinline__ float2 load_now(const LoadOp& load, const LineId& id, int l, int64_t base, unsigned off) {
+    if constexpr (fetch_count<LoadOp>::value == 2)
+        return load.post(id, l, load.fetch(id, l, base, off), load.fetch2(id, l, base, off));
+    else
+        return load.post(id, l, load.fetch(id, l, base, off));
+}
+
 // Runtime-radix fallback for lengths without a specialisation (same functor contracts).
 template <class LoadOp, class StoreOp>
 __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load, StoreOp store) {
@@ -223,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             float2 v = make_float2(0.f, 0.f);
             if (w < wvalid) {
                 id.i = i0 + w;
-                v = load.post(id, l, load.fetch(id, l, in_base, (unsigned)(w * p.in_i + l)));
+                v = load_now(load, id, l, in_base, (unsigned)(w * p.in_i + l));
             }
             tile[l * W + (w ^ (l & (W - 1)))] = v;
         }
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             float2 v = make_float2(0.f, 0.f);
             if (w < wvalid) {
                 id.i = i0 + w;
-                v = load.post(id, l, load.fetch(id, l, in_base, (unsigned)(l * p.in_l + w * p.in_i)));
+                v = load_now(load, id, l, in_base, (unsigned)(l * p.in_l + w * p.in_i));
             }
             tile[l * W + w] = v;
         }
@@ -395,7 +410,9 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
     const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
 
     // ---- global loads: all issued before anything waits -----------------------------------
+    constexpr int NF = fetch_count<LoadOp>::value;
     float2 v[nld];
+    float2 v2[NF == 2 ? nld : 1];
     if constexpr (ROWS) {
 #pragma unroll
         for (int it = 0; it < nld; ++it) {
@@ -405,6 +422,7 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
             const int wc = wl < wvalid ? wl : 0;     // clamped: always a valid line
             id.i = i0 + wc;
             v[it] = load.fetch(id, l, in_base, (unsigned)wc * in_i + (unsigned)l);
+            if constexpr (NF == 2) v2[it] = load.fetch2(id, l, in_base, (unsigned)wc * in_i + (unsigned)l);
         }
     } else {
         const int wc = w < wvalid ? w : 0;
@@ -417,6 +435,7 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
             for (int q = 0; q < R0; ++q) {
                 const int l = b + q * m0;
                 v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
+                if constexpr (NF == 2) v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
             }
         }
     }
@@ -429,7 +448,9 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
             const int e = tid + T * it;
             const int wl = e / L, l = e - wl * L;
             id.i = i0 + wl;
-            float2 x = load.post(id, l, v[it]);
+            float2 x;
+            if constexpr (NF == 2) x = load.post(id, l, v[it], v2[it]);
+            else x = load.post(id, l, v[it]);
             if (wl >= wvalid) x = make_float2(0.f, 0.f);
             if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
         }
@@ -445,7 +466,8 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
                 float2* x = &v[it * R0];
 #pragma unroll
                 for (int q = 0; q < R0; ++q) {
-                    x[q] = load.post(id, b + q * m0, x[q]);
+                    if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
+                    else x[q] = load.post(id, b + q * m0, x[q]);
                     if (w >= wvalid) x[q] = make_float2(0.f, 0.f);
                 }
                 dft_p<R0>(x);
@@ -542,17 +564,23 @@ struct StorePlainT {
 // Lengths with a compile-time specialisation (radices listed first stage first; they must
 // match choose_radices() in fft_engine.hip).  Other lengths run the generic kernel.
 #define RCFM_FFT_FAST_LENGTHS(X) \
+    X(75, 5, 5, 3, 1)            \
     X(80, 10, 8, 1, 1)           \
     X(100, 10, 10, 1, 1)         \
     X(120, 10, 6, 2, 1)          \
     X(125, 5, 5, 5, 1)           \
     X(128, 8, 8, 2, 1)           \
+    X(150, 10, 5, 3, 1)          \
     X(160, 10, 8, 2, 1)          \
+    X(192, 8, 8, 3, 1)           \
     X(200, 10, 10, 2, 1)         \
     X(240, 10, 8, 3, 1)          \
     X(250, 10, 5, 5, 1)          \
     X(256, 8, 8, 4, 1)           \
+    X(300, 10, 6, 5, 1)          \
     X(320, 10, 8, 4, 1)          \
+    X(375, 5, 5, 5, 3)           \
+    X(384, 8, 8, 6, 1)           \
     X(400, 10, 10, 4, 1)         \
     X(480, 10, 8, 6, 1)          \
     X(500, 10, 10, 5, 1)         \

@@ -31,6 +31,13 @@ void fused_real_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, 
 void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
                             int count, hipStream_t s);
 
+// The same two stages for real signals transformed two at a time: U2 [ceil(count/2)][n] =
+// FFT(x[2c] + j x[2c+1]); the Hilbert load of channel c unpacks its own spectrum from U2.
+// U2 must not alias u (u is written while other channels still read their pair).
+void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2* tmp, int count, hipStream_t s);
+void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const float* m, float2* u, float2* tmp,
+                                 int count, hipStream_t s);
+
 // Forward FFT whose last pass stores only the bins |k| <= keep (decimation to A needs no more).
 void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,
                       hipStream_t s);

@@ -21,7 +21,7 @@ struct LoadTunerGather {
     const float2* X;
     const int64_t* roll;
     int64_t N;
-    double inv_n;
+    float two_pi_over_n, delta;
     float a0;
     int B, nyq, nneg, nyq_mode;
     int64_t line_stride;   // in_l of the pass: k = l * line_stride + i
@@ -38,11 +38,16 @@ struct LoadTunerGather {
         return i < 0 ? i + N : i;
     }
     // fftshift(get_window(...))[src] = a0 - (1 - a0) cos(2 pi ((src - N//2) mod N) / N)
+    //                                = a0 + (1 - a0) cos(2 pi d / N + delta),  d = src or src - N (signed,
+    // |d| <= N/2), delta = pi / N for odd N.  In the hot case |theta| < 0.06: a 4-term series is exact
+    // to 1e-14; otherwise the library cosine.
     __device__ __forceinline__ float window(int64_t src) const {
-        int64_t i = src - N / 2;
-        if (i < 0) i += N;
-        const float frac = (float)((double)i * inv_n);
-        return a0 - (1.f - a0) * cospif(2.f * frac);
+        const int64_t dsrc = (src <= N / 2) ? src : src - N;
+        const float th = (float)dsrc * two_pi_over_n + delta;
+        const float t2 = th * th;
+        const float series = 1.f - t2 * 0.5f * (1.f - t2 * (1.f / 12.f) * (1.f - t2 * (1.f / 30.f)));
+        const float c = (fabsf(th) < 0.06f) ? series : cosf(th);
+        return a0 + (1.f - a0) * c;
     }
     __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
         const int64_t src = source_bin((int)(base + off));   // in_batch = 0: base + off = bin inside the channel
@@ -75,6 +80,51 @@ struct LoadRealAsComplex {
     __device__ __forceinline__ float2 post(const LineId&, int, float2 v) const { return v; }
 };
 
+// Two real signals per complex FFT: u = x_even + j x_odd.
+struct LoadRealPair {
+    const float* x;
+    int n, count;
+    __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
+        // in_batch = 0: base + off = sample index inside the signal
+        const int c0 = 2 * id.batch, c1 = (c0 + 1 < count) ? c0 + 1 : c0;
+        const int64_t a = base + off;
+        return make_float2(x[(int64_t)c0 * n + a], x[(int64_t)c1 * n + a]);
+    }
+    __device__ __forceinline__ float2 post(const LineId&, int, float2 v) const { return v; }
+};
+
+// Hilbert mask applied to one member of such a pair: with U = FFT(x0 + j x1),
+// X0[k] = (U[k] + conj U[-k]) / 2, X1[k] = (U[k] - conj U[-k]) / 2j; Z = h X, bins above n/2 are 0.
+struct LoadHilbertPair {
+    static constexpr int kFetches = 2;
+    const float2* U;     // [ceil(count / 2)][n]
+    int n;
+    int64_t line_stride;
+    __device__ __forceinline__ int bin(const LineId&, int64_t base, unsigned off) const {
+        return (int)(base + off);   // in_batch = 0
+    }
+    __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
+        const int k = bin(id, base, off);
+        return U[(int64_t)(id.batch >> 1) * n + (k <= n / 2 ? k : 0)];
+    }
+    __device__ __forceinline__ float2 fetch2(const LineId& id, int, int64_t base, unsigned off) const {
+        const int k = bin(id, base, off);
+        return U[(int64_t)(id.batch >> 1) * n + ((k <= n / 2 && k > 0) ? n - k : 0)];
+    }
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 a, float2 b) const {
+        const int k = (int)(l * line_stride + id.i);
+        float h = 0.f;
+        if (k == 0) h = 1.f;
+        else if (k < (n + 1) / 2) h = 2.f;
+        else if ((n & 1) == 0 && k == n / 2) h = 1.f;
+        h *= 0.5f;
+        float2 xk;
+        if ((id.batch & 1) == 0) xk = make_float2(a.x + b.x, a.y - b.y);          // U[k] + conj U[-k]
+        else xk = make_float2(a.y + b.y, -(a.x - b.x));                           // (U[k] - conj U[-k]) / j
+        return make_float2(xk.y * h, xk.x * h);   // swapped: inverse transform
+    }
+};
+
 // scipy.signal.hilbert's mask on the full spectrum U: h = {1, 2, ..., 2, (1), 0, ...}.
 struct LoadHilbertMask {
     const float2* U;
@@ -104,9 +154,9 @@ struct StoreStereoMix {
         const int64_t a = base + off;
         // z = (v.y, v.x); Im(z^2)/|z^2| = 2 ab / (a^2 + b^2), pre-scaled against underflow;
         // z == 0 gives NaN like pll.py:57-58
-        const float s = fmaxf(fabsf(v.x), fabsf(v.y));
-        const float za = v.y / s, zb = v.x / s;
-        const float s2 = (2.f * za * zb) / (za * za + zb * zb);
+        const float inv = __frcp_rn(fmaxf(fabsf(v.x), fabsf(v.y)));
+        const float za = v.y * inv, zb = v.x * inv;
+        const float s2 = (2.f * za * zb) * __frcp_rn(za * za + zb * zb);
         const float mm = m[a];
         const float lmr = (s2 * mm) * 1.0175f;
         u[a] = make_float2(mm + lmr, mm - lmr);
@@ -151,7 +201,8 @@ void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, flo
     ld.X = g.X;
     ld.roll = g.roll;
     ld.N = g.N;
-    ld.inv_n = 1.0 / (double)g.N;
+    ld.two_pi_over_n = (float)(6.28318530717958647692 / (double)g.N);
+    ld.delta = (g.N % 2) ? (float)(3.14159265358979323846 / (double)g.N) : 0.f;
     ld.a0 = (float)g.a0;
     ld.B = (int)B;
     ld.nyq = g.nyq;
@@ -189,6 +240,34 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
     LoadHilbertMask ld{U, (int)n, e.desc().pass[0].in_l};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
     fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    StoreStereoMix stl{m, u};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+}
+
+void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    const int pairs = (count + 1) / 2;
+    LoadRealPair ld{x, (int)n, count};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, n), pairs, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, pairs, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    fftk::StorePlainT<false> stl{U, 1.0f};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), pairs, ldl, stl, s);
+}
+
+void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
+                                 int count, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    LoadHilbertPair ld{U, (int)n, e.desc().pass[0].in_l};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, n), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StoreStereoMix stl{m, u};

@@ -52,6 +52,11 @@ void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipS
 void launch_pilot_stage(const float2* iq, const float* x, float* m_out, float* p_out, int64_t n,
                         int batch, const float* g, int H, float side_tap, hipStream_t stream);
 
+// The same chain specialised for WBFM's 41-tap pilot filter (H = 40); g_host: 41 taps on the host.
+// Needs n % 4 == 0 (16-byte stores) and n > 123.
+void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
+                            const float* g_host, float side_tap, hipStream_t stream);
+
 // wbfm.py:83,86-87: s2 = Im(z^2)/|z^2|; lmr = s2 m 1.0175; u = (m + lmr) + j (m - lmr).
 void launch_stereo_mix(const float2* z, const float* m, float2* u, size_t count, hipStream_t stream);
 

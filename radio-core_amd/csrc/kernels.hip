@@ -239,6 +239,111 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage(const float2* __restri
     }
 }
 
+// Register-blocked version for the 41-tap pilot filter (H = 40), the WBFM hot path.
+// Each thread produces 8 consecutive outputs from an 88-sample window held in registers
+// (22 ds_read_b128 instead of 648 ds_read_b32); the 41 distinct taps arrive as kernel
+// arguments (SGPRs).  Blocks that touch either end of the buffer take the reflecting path.
+struct PilotTaps {
+    float g[41];
+};
+
+constexpr int kPilotPer = 8;
+constexpr int kPilotFastTile = kThreads * kPilotPer;   // 2048 outputs per workgroup
+
+__global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const float2* __restrict__ iq,
+                                                              float* __restrict__ m_out,
+                                                              float* __restrict__ p_out, int64_t n,
+                                                              PilotTaps taps, float side_tap) {
+    constexpr int H = 40, T = kPilotFastTile, PER = kPilotPer;
+    __shared__ __attribute__((aligned(16))) float m_s[T + 2 * H];        // m[q0 + s]
+    __shared__ __attribute__((aligned(16))) float d_s[T + 2 * H + 2];    // d[q0 - 1 + s] (circular)
+    const int c = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * T;
+    const int64_t q0 = t0 - H;
+    const float2* xc = iq + (int64_t)c * n;
+    // discriminator: both samples of every pair are fetched unconditionally (clamped index) and
+    // up front, 18 loads in flight per thread; a load inside the loop's `if` would serialise
+    // one HBM round trip per iteration
+    constexpr int ND = (T + 2 * H + 2 + kThreads - 1) / kThreads;
+    float2 xa[ND], xb[ND];
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+        int64_t i = q0 - 1 + tid + kThreads * it;
+        if (i == -1) i = n - 1;   // the same-size Decimate is circular (decimate.py:48)
+        if (i == n) i = 0;
+        i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
+        xa[it] = xc[i];
+        xb[it] = xc[i - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+        const int s = tid + kThreads * it;
+        const int64_t i = q0 - 1 + s;
+        // d[0] = 0 (fm.py:64); i == n wraps to d[0]; outside [-1, n] is never read
+        const bool live = (i == -1) || (i > 0 && i < n);
+        const float v = live ? phase_step(xa[it], xb[it]) : 0.f;
+        if (s < T + 2 * H + 2) d_s[s] = v;
+    }
+    __syncthreads();
+    for (int s = tid; s < T + 2 * H; s += kThreads) {
+        const int64_t q = q0 + s;
+        float v = 0.f;
+        if (q >= 0 && q < n) {
+            v = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
+            if (q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
+        }
+        m_s[s] = v;
+    }
+    __syncthreads();
+
+    const int64_t last = n - 1;
+    const int o = tid * PER;
+    if (t0 - H >= 0 && t0 + T - 1 + H <= last) {   // workgroup-uniform: no reflection anywhere in the tile
+        float w[PER + 2 * H];
+#pragma unroll
+        for (int j = 0; j < (PER + 2 * H) / 4; ++j) {
+            float4 q4 = *reinterpret_cast<const float4*>(&m_s[o + 4 * j]);
+            // pin the 16-byte read: left alone, the scheduler re-reads the window piecemeal with
+            // ds_read2_b32 at an 8-dword lane stride (8-way bank conflicts)
+            asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w));
+            w[4 * j] = q4.x;
+            w[4 * j + 1] = q4.y;
+            w[4 * j + 2] = q4.z;
+            w[4 * j + 3] = q4.w;
+        }
+        float acc[PER];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) acc[r] = taps.g[H] * w[r];
+        // plain 81-tap FMAs: the symmetric form (one add per tap pair) saves no instruction and
+        // makes the scheduler hoist 320 pair sums into registers (256 VGPRs, 1 wave per SIMD)
+#pragma unroll
+        for (int j = 1; j <= 2 * H; ++j) {
+            const float gj = taps.g[j <= H ? H - j : j - H];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) acc[r] = fmaf(gj, w[r + j], acc[r]);
+        }
+        float4* dst = reinterpret_cast<float4*>(p_out + (int64_t)c * n + t0 + o);
+        dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        return;
+    }
+    const float m_first = (q0 <= 0) ? m_s[0 - q0] : 0.f;
+    const float m_last = (last - q0 < T + 2 * H) ? m_s[last - q0] : 0.f;
+    for (int r = 0; r < PER; ++r) {
+        const int64_t i = t0 + o + r;
+        if (i >= n) break;
+        float acc = taps.g[0] * m_s[o + r + H];
+        for (int j = 1; j <= H; ++j) {
+            const int64_t ql = i - j, qr = i + j;
+            const float el = (ql < 0) ? 2.f * m_first - m_s[-ql - q0] : m_s[ql - q0];
+            const float er = (qr > last) ? 2.f * m_last - m_s[2 * last - qr - q0] : m_s[qr - q0];
+            acc = fmaf(taps.g[j], el + er, acc);
+        }
+        p_out[(int64_t)c * n + i] = acc;
+    }
+}
+
 // z and u may be the same buffer (element i only depends on element i).
 __global__ __launch_bounds__(kThreads) void k_stereo_mix(const float2* z, const float* __restrict__ m,
                                                          float2* u, size_t count) {
@@ -420,6 +525,16 @@ void launch_stereo_unpack(const float2* U, int64_t B, float2* V, int64_t A, int 
 void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipStream_t stream) {
     if (batch <= 0) return;
     hipLaunchKernelGGL(k_discriminator, grid2(n, kThreads, batch), dim3(kThreads), 0, stream, iq, d, n);
+    RC_LAUNCH_CHECK();
+}
+
+void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
+                            const float* g_host, float side_tap, hipStream_t stream) {
+    if (batch <= 0) return;
+    PilotTaps taps;
+    for (int i = 0; i <= 40; ++i) taps.g[i] = g_host[i];
+    hipLaunchKernelGGL(k_pilot_stage_h40, grid2(n, kPilotFastTile, batch), dim3(kThreads), 0, stream, iq, m_out,
+                       p_out, n, taps, side_tap);
     RC_LAUNCH_CHECK();
 }
 
