@@ -208,8 +208,8 @@ def main():
     x, centres, f_in = synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
 
     # this rank's contiguous share of the channels
-    lo = rank * C // world
-    hi = (rank + 1) * C // world
+    from radiocore.tools import sharding
+    lo, hi = sharding.channel_range(rank, world, C)
     mine = hi - lo
     rolls = [int(f_in - f) for f in centres]
     roll_a = (ctypes.c_int64 * C)(*rolls)
@@ -220,10 +220,7 @@ def main():
     kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
     hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
     audio = torch.empty((mine, A, ch), dtype=torch.float32, device="cuda")
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty((((r + 1) * C // world) - (r * C // world), A, ch), dtype=torch.float32,
-                                device="cuda") for r in range(world)] if rank == 0 else None
+    gathered = torch.empty((C, A, ch), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
 
     def step():
         s = hip.stream()
@@ -231,7 +228,7 @@ def main():
         # pipeline_run addresses channels of tuner and demod by the same index
         hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), s))
         if world > 1:
-            dist.gather(audio, gathered, dst=0)          # RCCL over xGMI: the only collective on the path
+            sharding.gather_audio(audio, C, dst=0, out=gathered)   # RCCL over xGMI: the only collective on the path
 
     def barrier():
         torch.cuda.synchronize()

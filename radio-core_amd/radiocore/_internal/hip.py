@@ -107,8 +107,19 @@ def load_library(path=LIB_PATH):
 
 
 def lib():
+    """The process-wide librcfm handle.
+
+    PyTorch's ROCm wheel bundles its own libamdhip64; librcfm.so needs the system one.  Two
+    HIP runtimes in one process fight over the device (whichever initialises second reports
+    "no ROCm-capable device").  Importing torch first makes the dynamic linker resolve
+    librcfm's libamdhip64.so.7 dependency to the copy torch already loaded: one runtime.
+    """
     global _lib
     if _lib is None:
+        try:
+            import torch as _t  # noqa: F401  (load order matters, see above)
+        except ImportError:
+            pass
         _lib = load_library()
     return _lib
 

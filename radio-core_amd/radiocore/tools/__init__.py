@@ -1,3 +1,4 @@
 """Imports all modules from radiocore.tools."""
 
 from radiocore.tools.tuner import *
+from radiocore.tools.sharding import *

@@ -1,0 +1,85 @@
+"""CPU, world_size 2, gloo: the channel-sharded path of bench.py --gpus N.
+
+Each rank demodulates its own channel range (here with the oracle standing in for the GPU,
+this container has none) and the blocks are gathered to rank 0 exactly as bench.py does with
+RCCL; the result must equal the single-process loop.
+"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+N, B, A = 600000, 60000, 12000
+CENTRES = [100.00e6, 100.05e6, 99.93e6, 100.12e6, 99.85e6]     # 5 channels over 2 ranks: 2 + 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _audio_for(channel_ids):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import radiocore_oracle as oracle
+    import workloads
+    tuner = oracle.Tuner()
+    for f in CENTRES:
+        tuner.add_channel(f, B, None)
+    tuner.request_bandwidth(float(N))
+    x = workloads.wideband(N, tuner.input_frequency, CENTRES, B, gain=0.4)
+    tuner.load(x)                                    # the wideband FFT is replicated on every rank
+    out = [oracle.MFM(B, A).run(tuner.run_pruned(i)) for i in channel_ids]
+    return np.stack(out) if out else np.zeros((0, A, 1), np.float32)
+
+
+def _worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.join(ROOT, "radio-core_amd", "radiocore", "tools"))
+    import sharding                                   # plain module: no GPU needed to import it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.channel_range(rank, world, len(CENTRES))
+    local = torch.from_numpy(_audio_for(range(lo, hi)))
+    full = sharding.gather_audio(local, len(CENTRES), dst=0)
+    dist.barrier()
+    if rank == 0:
+        np.save(result_path, full.numpy())
+    else:
+        assert full is None
+    dist.destroy_process_group()
+
+
+def test_channel_ranges_cover_everything_once():
+    sys.path.insert(0, os.path.join(ROOT, "radio-core_amd", "radiocore", "tools"))
+    import sharding
+    for world in (1, 2, 3, 4, 8):
+        for C in (1, 5, 64, 1024, 8192):
+            edges = [sharding.channel_range(r, world, C) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == C
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            assert sum(sharding.channel_counts(world, C)) == C
+    with pytest.raises(ValueError):
+        sharding.channel_range(2, 2, 10)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_equals_single_process(tmp_path):
+    result = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(2, _free_port(), result), nprocs=2, join=True)
+    got = np.load(result)
+    want = _audio_for(range(len(CENTRES)))
+    assert got.shape == want.shape == (len(CENTRES), A, 1)
+    assert np.array_equal(got, want)
