@@ -364,6 +364,26 @@ struct rcfm_demod_s {
         RC_HIP(hipStreamSynchronize(s));
     }
 
+    // mfm.py:63-65 / wbfm.py:90-100: de-emphasis (per-leg state), joint DC removal, clip.
+    void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s) {
+        const bool fast = ((int64_t)A * ch) % 4 == 0;
+        {
+            StageTimer tm(ST_DEEMPH, s);
+            if (fast)
+                launch_fir51(v, audio, A, ch, cnt, taps_h, st, partial.as<float>(), s);
+            else
+                launch_fir(v, audio, A, ch, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
+        }
+        {
+            StageTimer tm(ST_DEEMPH_STATE, s);
+            launch_fir_state(v, A, ch, cnt, taps.as<float>(), 51, st, s);
+        }
+        {
+            StageTimer tm(ST_DC_CLIP, s);
+            launch_dc_clip(audio, A, ch, cnt, partial.as<float>(), fast ? fir51_tiles(A, ch) : tiles * ch, s);
+        }
+    }
+
     void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s) {
         size_t need = 0;
         if (kind == RCFM_WBFM) {
@@ -414,19 +434,7 @@ struct rcfm_demod_s {
                     eng_A->c2c(V, V, TA, cnt, true, 1.0f, s);   // -> [cnt][A][2] float32, L/R interleaved
                 }
                 float* st = state.as<float>() + (size_t)first * ch * 50;
-                {
-                    StageTimer tm(ST_DEEMPH, s);
-                    launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
-                               partial.as<float>(), s);
-                }
-                {
-                    StageTimer tm(ST_DEEMPH_STATE, s);
-                    launch_fir_state(reinterpret_cast<float*>(V), A, 2, cnt, taps.as<float>(), 51, st, s);
-                }
-                {
-                    StageTimer tm(ST_DC_CLIP, s);
-                    launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles, s);
-                }
+                run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s);
                 return;
             }
             // wbfm.py:80 / pll.py:34  analytic signal of the pilot
@@ -473,7 +481,7 @@ struct rcfm_demod_s {
             }
             {
                 StageTimer tm(ST_DC_CLIP, s);
-                launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles, s);
+                launch_dc_clip(audio, A, 2, cnt, partial.as<float>(), tiles * 2, s);
             }
             return;
         }
@@ -502,18 +510,7 @@ struct rcfm_demod_s {
             }
             if (kind == RCFM_FM) return;
             float* st = state.as<float>() + (size_t)first * 50;
-            {
-                StageTimer tm(ST_DEEMPH, s);
-                launch_fir(dst, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
-            }
-            {
-                StageTimer tm(ST_DEEMPH_STATE, s);
-                launch_fir_state(dst, A, 1, cnt, taps.as<float>(), 51, st, s);
-            }
-            {
-                StageTimer tm(ST_DC_CLIP, s);
-                launch_dc_clip(audio, A, 1, cnt, partial.as<float>(), tiles, s);
-            }
+            run_deemph(dst, audio, st, cnt, s);
             return;
         }
         FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);

@@ -203,6 +203,20 @@ __device__ __forceinline__ float2 load_now(const LoadOp& load, const LineId& id,
         return load.post(id, l, load.fetch(id, l, base, off));
 }
 
+// A StoreOp may need one auxiliary input value per output point (kAux: fetch_aux(id, k, base, off)
+// is issued with the tile's loads, operator() receives the value as a sixth argument).
+template <class T, class = void>
+struct has_aux : std::false_type {};
+template <class T>
+struct has_aux<T, std::void_t<decltype(T::kAux)>> : std::true_type {};
+
+template <class StoreOp>
+__device__ __forceinline__ void store_now(const StoreOp& store, const LineId& id, int k, int64_t base, unsigned off,
+                                          float2 v) {
+    if constexpr (has_aux<StoreOp>::value) store(id, k, base, off, v, store.fetch_aux(id, k, base, off));
+    else store(id, k, base, off, v);
+}
+
 // Runtime-radix fallback for lengths without a specialisation (same functor contracts).
 template <class LoadOp, class StoreOp>
 __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load, StoreOp store) {
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
         float2 v = tile[row * W + (w ^ (swz & row & (W - 1)))];
         if (p.has_twiddle) v = cmul(v, big_twiddle(d, (tw_base + (unsigned)w * (unsigned)p.tw_i) * (unsigned)k));
         id.i = i0 + w;
-        store(id, k, out_base, (unsigned)(k * p.out_k + w * p.out_i), v);
+        store_now(store, id, k, out_base, (unsigned)(k * p.out_k + w * p.out_i), v);
     }
 }
 
@@ -441,6 +455,42 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
     }
     for (int e = tid; e < L; e += T) tw[e] = d.stage_tw[e];
 
+    // Output index of slot 0 of last-stage block g (see the last stage below).
+    constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
+    auto kbase = [](int g) -> int {
+        if constexpr (S == 2) {
+            return g;
+        } else if constexpr (S == 3) {
+            constexpr int w1 = L / (R0 * RL);
+            const int q1 = g / w1, q2 = g - q1 * w1;
+            return q1 + R0 * q2;
+        } else {
+            constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
+            const int q1 = g / w1, r1 = g - q1 * w1;
+            const int q2 = r1 / w2, q3 = r1 - q2 * w2;
+            return q1 + R0 * (q2 + R1 * q3);
+        }
+    };
+    // Auxiliary inputs of the store functor (e.g. m[n] of the stereo mix) travel with the tile's
+    // loads instead of costing a dependent round trip inside the store loop.
+    constexpr bool AUX = has_aux<StoreOp>::value;
+    float aux[AUX ? nitL * RL : 1];
+    if constexpr (AUX) {
+        const int wc = w < wvalid ? w : 0;
+        id.i = i0 + wc;
+#pragma unroll
+        for (int it = 0; it < nitL; ++it) {
+            int g = rg + RG * it;
+            if (rowsL % RG != 0) g = g < rowsL ? g : 0;
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const int k = kb + (L / RL) * q;
+                aux[it * RL + q] = store.fetch_aux(id, k, out_base, (unsigned)k * out_k + (unsigned)wc);
+            }
+        }
+    }
+
     // ---- first stage ---------------------------------------------------------------------
     if constexpr (ROWS) {
 #pragma unroll
@@ -493,7 +543,6 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
     // L/(r_1 RL), L/(r_1 r_2 RL), ...; kb = q_1 + r_1 q_2 + r_1 r_2 q_3.
     // Inter-pass twiddle W_n^(f k), f = this lane's line factor: W_n^(f kb) once per butterfly,
     // then successive powers of D = W_n^(f L / RL) (RL - 1 <= 9 multiplications).
-    constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
     const unsigned f = (unsigned)(id.o1 * p.tw_o1 + id.o2 * p.tw_o2 + (int64_t)(i0 + w) * p.tw_i);
     float2 D = make_float2(1.f, 0.f);
     if constexpr (!ROWS) D = big_twiddle(d, f * (unsigned)(L / RL));
@@ -507,19 +556,7 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<ROWS>(g * RL + q, w)];
             dft_p<RL>(x);
-            int kb;
-            if constexpr (S == 2) {
-                kb = g;
-            } else if constexpr (S == 3) {
-                constexpr int w1 = L / (R0 * RL);
-                const int q1 = g / w1, q2 = g - q1 * w1;
-                kb = q1 + R0 * q2;
-            } else {
-                constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
-                const int q1 = g / w1, r1 = g - q1 * w1;
-                const int q2 = r1 / w2, q3 = r1 - q2 * w2;
-                kb = q1 + R0 * (q2 + R1 * q3);
-            }
+            const int kb = kbase(g);
             float2 Tw = make_float2(1.f, 0.f);
             if constexpr (!ROWS) Tw = big_twiddle(d, f * (unsigned)kb);
             if (lane_ok) {
@@ -531,7 +568,8 @@ __global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, Store
                         y = cmul(y, Tw);
                         Tw = cmul(Tw, D);
                     }
-                    store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
+                    if constexpr (AUX) store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y, aux[it * RL + q]);
+                    else store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
                 }
             }
         }

@@ -148,18 +148,21 @@ struct LoadHilbertMask {
 
 // Last pass of the analytic-signal IFFT: z (still swapped) -> stereo mix -> packed u.
 struct StoreStereoMix {
+    static constexpr bool kAux = true;   // m[n] is fetched with the tile's loads
     const float* m;
     float2* u;
-    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
-        const int64_t a = base + off;
+    __device__ __forceinline__ float fetch_aux(const LineId&, int, int64_t base, unsigned off) const {
+        return (m + base)[off];
+    }
+    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v,
+                                               float mm) const {
         // z = (v.y, v.x); Im(z^2)/|z^2| = 2 ab / (a^2 + b^2), pre-scaled against underflow;
         // z == 0 gives NaN like pll.py:57-58
         const float inv = __frcp_rn(fmaxf(fabsf(v.x), fabsf(v.y)));
         const float za = v.y * inv, zb = v.x * inv;
         const float s2 = (2.f * za * zb) * __frcp_rn(za * za + zb * zb);
-        const float mm = m[a];
         const float lmr = (s2 * mm) * 1.0175f;
-        u[a] = make_float2(mm + lmr, mm - lmr);
+        (u + base)[off] = make_float2(mm + lmr, mm - lmr);
     }
 };
 

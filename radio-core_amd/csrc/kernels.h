@@ -70,11 +70,17 @@ void launch_pll_phase(const float2* z, size_t count, double mult, int want_imag,
 int fir_tiles(int64_t n);
 void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const float* taps, int nb,
                 const float* state, float* partial, hipStream_t stream);
+// The 51-tap de-emphasis case, register-blocked (n*ch % 4 == 0 for its 16-byte stores);
+// partial: [batch][fir51_tiles(n, ch)] (both stereo legs share a tile).  taps_host: 51 floats.
+int fir51_tiles(int64_t n, int ch);
+void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const float* taps_host,
+                  const float* state, float* partial, hipStream_t stream);
 // Advance `state` to the end of the buffer (must run after launch_fir on the stream).
 void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
                       float* state, hipStream_t stream);
 // mfm.py:64-65 / wbfm.py:97-100: y -= mean(y) over the channel's n*ch samples; clip +-0.999.
-void launch_dc_clip(float* y, int64_t n, int ch, int batch, const float* partial, int tiles,
+// partial: [batch][nparts] partial sums of y.
+void launch_dc_clip(float* y, int64_t n, int ch, int batch, const float* partial, int nparts,
                     hipStream_t stream);
 
 }  // namespace rcfm

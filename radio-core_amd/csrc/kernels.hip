@@ -435,6 +435,91 @@ __global__ __launch_bounds__(kThreads) void k_fir(const float* __restrict__ x, f
     }
 }
 
+// De-emphasis FIR specialised for its 51 taps, on the interleaved stream z[i*CH + h]:
+// y[e] = sum_j b[j] z[e - CH j].  Each thread produces 8 consecutive interleaved outputs (one
+// 32-byte store) from a register window read with pinned ds_read_b128; taps arrive in SGPRs.
+struct DeemphTaps {
+    float b[51];
+};
+
+constexpr int kFirPer = 8;
+constexpr int kFirFastTile = kThreads * kFirPer;   // 2048 interleaved outputs per workgroup
+
+template <int CH>
+__global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x, float* __restrict__ y,
+                                                    int64_t total, DeemphTaps taps,
+                                                    const float* __restrict__ state,
+                                                    float* __restrict__ partial) {
+    constexpr int T = kFirFastTile, PER = kFirPer, HIST = 50 * CH;
+    constexpr int NW = (PER + HIST + 3) / 4;                       // float4 reads per thread
+    __shared__ __attribute__((aligned(16))) float x_s[T + NW * 4];  // z[t0 - HIST + s]
+    __shared__ float red[kThreads / 64];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * T;
+    const float* xc = x + (int64_t)c * total;
+    float* yc = y + (int64_t)c * total;
+    constexpr int NL = (T + HIST + kThreads - 1) / kThreads;
+    float v[NL];
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {                              // unconditional, clamped loads
+        const int64_t e = t0 - HIST + tid + kThreads * it;
+        v[it] = xc[e < 0 ? 0 : (e > total - 1 ? total - 1 : e)];
+    }
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+        const int s = tid + kThreads * it;
+        const int64_t e = t0 - HIST + s;
+        if (s < T + NW * 4) x_s[s] = (e >= 0 && e < total) ? v[it] : 0.f;
+    }
+    __syncthreads();
+    const int o = tid * PER;
+    float w[NW * 4];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        float4 q4 = *reinterpret_cast<const float4*>(&x_s[o + 4 * j]);
+        asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w));   // keep the 16-byte reads
+        w[4 * j] = q4.x;
+        w[4 * j + 1] = q4.y;
+        w[4 * j + 2] = q4.z;
+        w[4 * j + 3] = q4.w;
+    }
+    float acc[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j <= 50; ++j) {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], w[r + HIST - CH * j], acc[r]);
+    }
+    float local = 0.f;
+    const int64_t e0 = t0 + o;
+    if (e0 < HIST) {                                               // lfilter's initial conditions
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int64_t e = e0 + r;
+            if (e < HIST && e < total) acc[r] += state[(int64_t)c * HIST + (e % CH) * 50 + e / CH];
+        }
+    }
+    if (e0 + PER <= total) {
+        float4* dst = reinterpret_cast<float4*>(yc + e0);
+        dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+        for (int r = 0; r < PER; ++r) local += acc[r];
+    } else {
+        for (int r = 0; r < PER; ++r)
+            if (e0 + r < total) {
+                yc[e0 + r] = acc[r];
+                local += acc[r];
+            }
+    }
+    if (partial != nullptr) {
+        const float t = block_sum(local, red);
+        if (tid == 0) partial[(int64_t)c * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 __global__ __launch_bounds__(128) void k_fir_state(const float* __restrict__ x, int64_t n, int ch,
                                                    const float* __restrict__ taps, int nb,
                                                    float* __restrict__ state) {
@@ -575,6 +660,21 @@ void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const fl
     RC_LAUNCH_CHECK();
 }
 
+int fir51_tiles(int64_t n, int ch) { return (int)((n * ch + kFirFastTile - 1) / kFirFastTile); }
+
+void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const float* taps_host,
+                  const float* state, float* partial, hipStream_t stream) {
+    if (batch <= 0 || n <= 0) return;
+    DeemphTaps taps;
+    for (int i = 0; i < 51; ++i) taps.b[i] = taps_host[i];
+    const dim3 grid((unsigned)fir51_tiles(n, ch), (unsigned)batch, 1);
+    if (ch == 2)
+        hipLaunchKernelGGL(k_fir51<2>, grid, dim3(kThreads), 0, stream, x, y, n * 2, taps, state, partial);
+    else
+        hipLaunchKernelGGL(k_fir51<1>, grid, dim3(kThreads), 0, stream, x, y, n, taps, state, partial);
+    RC_LAUNCH_CHECK();
+}
+
 void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
                       float* state, hipStream_t stream) {
     if (batch <= 0 || nb < 2) return;
@@ -583,12 +683,12 @@ void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float*
     RC_LAUNCH_CHECK();
 }
 
-void launch_dc_clip(float* y, int64_t n, int ch, int batch, const float* partial, int tiles,
+void launch_dc_clip(float* y, int64_t n, int ch, int batch, const float* partial, int nparts,
                     hipStream_t stream) {
     if (batch <= 0) return;
     const int64_t total = n * ch;
     hipLaunchKernelGGL(k_dc_clip, grid2(total, kThreads, batch), dim3(kThreads), 0, stream, y, total, partial,
-                       tiles * ch);
+                       nparts);
     RC_LAUNCH_CHECK();
 }
 
