@@ -397,7 +397,7 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
 //                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
 // StoreOp contract: operator()(id, k, tile_base, off, v).
 template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
-__global__ __launch_bounds__(T) void k_fft_tile(FftPassDev d, LoadOp load, StoreOp store) {
+__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load, StoreOp store) {
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
     constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;   // last radix
