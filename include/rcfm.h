@@ -159,6 +159,7 @@ typedef struct rcfm_fft_pass {
 typedef struct rcfm_fft_plan {
     int64_t n;
     int32_t npass, fine_bits;
+    int64_t tmp_stride; /* scratch elements per signal between passes (>= n) */
     rcfm_fft_pass pass[4];
 } rcfm_fft_plan;
 int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);

@@ -288,7 +288,7 @@ struct rcfm_tuner_s {
         const ResampleGeom& g = bd.geom;
         if (bd.engine) {
             // gather + window ride on the first pass of the inverse FFT (fused_passes.h)
-            band_tmp.reserve((size_t)count * B * sizeof(float2));
+            band_tmp.reserve((size_t)count * bd.engine->tmp_stride() * sizeof(float2));
             TunerGather tg{X.as<float2>(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode};
             StageTimer tm(ST_TUNER_IFFT, s);
             fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s);
@@ -346,8 +346,8 @@ struct rcfm_demod_s {
         if (use_engine() && fft_plan_describe(B, &probe) && fft_plan_describe(A, &probe)) {
             eng_B = std::make_unique<FftEngine>(B);
             eng_A = std::make_unique<FftEngine>(A);
-            buf_T.reset(c * B * sizeof(float2));
-            buf_TA.reset(c * A * sizeof(float2));
+            buf_T.reset(c * eng_B->tmp_stride() * sizeof(float2));
+            buf_TA.reset(c * eng_A->tmp_stride() * sizeof(float2));
             if (kind == RCFM_WBFM) buf_U2.reset(((c + 1) / 2) * B * sizeof(float2));
             if (kind != RCFM_WBFM) {
                 buf_Z.reset(c * B * sizeof(float2));   // full spectrum of the discriminator output
@@ -635,7 +635,7 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
         FftPlanDesc probe;
         if (use_engine() && fft_plan_describe(n, &probe)) {
             t->forward_engine = std::make_unique<FftEngine>(n);
-            t->forward_tmp.reset(sizeof(float2) * (size_t)n);
+            t->forward_tmp.reset(sizeof(float2) * (size_t)t->forward_engine->tmp_stride());
         } else {
             t->forward = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, 1, false);
             t->work.reserve(t->forward->work_bytes());
@@ -935,7 +935,7 @@ int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, v
         std::lock_guard<std::mutex> lock(mu);
         auto it = engines.find(n);
         if (it == engines.end()) it = engines.emplace(n, std::make_unique<FftEngine>(n)).first;
-        tmp.reserve((size_t)batch * n * sizeof(float2));
+        tmp.reserve((size_t)batch * it->second->tmp_stride() * sizeof(float2));
         it->second->c2c(static_cast<const float2*>(in), static_cast<float2*>(out), tmp.as<float2>(), batch,
                         inverse != 0, 1.0f, as_stream(stream));
     });

@@ -47,6 +47,10 @@ struct FftPlanDesc {
     int64_t n;
     int npass;
     int fine_bits;      // W_n^e = coarse[e >> fine_bits] * cis(-2 pi (e & mask) / n)
+    // Elements one signal occupies in the scratch buffer between passes.  Two-pass plans pad
+    // the scratch rows to a multiple of 16 points so that the first pass writes, and the last
+    // pass reads, whole 128-byte lines even when n_2 is not a multiple of 16 (B = 240 000 = 480 x 500).
+    int64_t tmp_stride;
     FftPass pass[kFftMaxPasses];
 };
 
@@ -73,8 +77,9 @@ class FftEngine {
     explicit FftEngine(int64_t n);
     const FftPlanDesc& desc() const { return desc_; }
     int npass() const { return desc_.npass; }
+    int64_t tmp_stride() const { return desc_.tmp_stride; }   // scratch elements per signal (>= n)
     // Unnormalised c2c transform of `batch` contiguous length-n signals (distance n).
-    // `tmp` holds batch*n complex values; in == out is allowed, tmp must be distinct.
+    // `tmp` holds batch * tmp_stride() complex values; in == out is allowed, tmp must be distinct.
     // inverse = conjugate transform (no 1/n); every output is multiplied by `scale`.
     void c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
              hipStream_t stream) const;

@@ -173,6 +173,13 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l) {
             p.load_along_l = 1;
         }
     }
+    d.tmp_stride = n;
+    if (np == 2 && (f[1] % 16) != 0) {
+        const int64_t pitch = (f[1] + 15) / 16 * 16;
+        d.pass[0].out_k = pitch;     // row k_1 of the scratch starts at k_1 * pitch
+        d.pass[1].in_i = pitch;
+        d.tmp_stride = f[0] * pitch;
+    }
     *out = d;
     return true;
 }
@@ -251,10 +258,11 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
     const int np = desc_.npass;
     const int64_t n = desc_.n;
     using namespace fftk;
+    const int64_t ts = desc_.tmp_stride;
     for (int t = 0; t < np; ++t) {
         const bool first = (t == 0), last = (t == np - 1);
         const float2* src = first ? in : tmp;
-        const FftPassDev dev = pass_dev(t, n, n);
+        const FftPassDev dev = pass_dev(t, first ? n : ts, last ? n : ts);
         if (last) {
             LoadPlainT<false> ld{src};
             if (inverse)

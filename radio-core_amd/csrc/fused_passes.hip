@@ -185,11 +185,11 @@ struct StoreRealPart {
 
 // Runs passes [first, last] of a plan with plain functors between tmp buffers.
 void middle_passes(const FftEngine& e, int from, int to, float2* tmp, int count, hipStream_t s) {
-    const int64_t n = e.desc().n;
+    const int64_t ts = e.tmp_stride();
     for (int t = from; t <= to; ++t) {
         fftk::LoadPlainT<false> ld{tmp};
         fftk::StorePlainT<false> st{tmp, 1.0f};
-        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(t, n, n), count, ld, st, s);
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(t, ts, ts), count, ld, st, s);
     }
 }
 
@@ -214,11 +214,11 @@ void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, flo
     ld.line_stride = e.desc().pass[0].in_l;
     // in_batch = 0: the load functor addresses X itself; `a` is the bin index inside the channel
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, B), count, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     fftk::StorePlainT<true> stl{out, (float)(1.0 / (double)g.N)};   // ifft (1/B) * (B/N)
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, B, B), count, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), B), count, ldl, stl, s);
 }
 
 void fused_real_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
@@ -228,11 +228,11 @@ void fused_real_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, 
     const int np = e.npass();
     LoadRealAsComplex ld{x};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, e.tmp_stride()), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StorePruned stl{U, (int)n, keep};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
 void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
@@ -242,11 +242,11 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
     const int np = e.npass();
     LoadHilbertMask ld{U, (int)n, e.desc().pass[0].in_l};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, e.tmp_stride()), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StoreStereoMix stl{m, u};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, hipStream_t s) {
@@ -256,11 +256,11 @@ void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* 
     const int pairs = (count + 1) / 2;
     LoadRealPair ld{x, (int)n, count};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, n), pairs, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, pairs, s);
     fftk::LoadPlainT<false> ldl{tmp};
     fftk::StorePlainT<false> stl{U, 1.0f};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), pairs, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), pairs, ldl, stl, s);
 }
 
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
@@ -270,11 +270,11 @@ void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U, const floa
     const int np = e.npass();
     LoadHilbertPair ld{U, (int)n, e.desc().pass[0].in_l};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, n), count, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StoreStereoMix stl{m, u};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
 void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,
@@ -284,11 +284,11 @@ void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2*
     const int np = e.npass();
     fftk::LoadPlainT<false> ld{in};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, e.tmp_stride()), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StorePruned stl{out, (int)n, keep};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
 void fused_ifft_real_out(const FftEngine& e, const float2* Y, float* y, float2* tmp, int count, float scale,
@@ -298,11 +298,11 @@ void fused_ifft_real_out(const FftEngine& e, const float2* Y, float* y, float2* 
     const int np = e.npass();
     fftk::LoadPlainT<true> ld{Y};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, n), count, ld, st0, s);
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, e.tmp_stride()), count, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StoreRealPart stl{y, scale};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, n, n), count, ldl, stl, s);
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
 }  // namespace rcfm

@@ -74,7 +74,7 @@ def run_pass(p, n, src, dst):
 
 def model_fft(x, plan):
     n = plan.n
-    tmp = np.zeros(n, np.complex128)
+    tmp = np.zeros(plan.tmp_stride, np.complex128)     # two-pass plans pad the scratch rows
     out = np.zeros(n, np.complex128)
     for t in range(plan.npass):
         p = plan.passes[t]
