@@ -322,6 +322,8 @@ struct rcfm_demod_s {
     ResampleGeom geom;   // B -> A, real, Hamming
     PlanCache r2c_B, c2c_inv_B, c2c_fwd_B, c2c_inv_A, c2r_A;
     std::unique_ptr<FftEngine> eng_B, eng_A;   // both set: the engine path with fused passes
+    std::unique_ptr<FftEngine> eng_Bi;         // eng_B's two pass lengths swapped (k_fft_tile2 pairing)
+    DeviceBuffer buf_Ti;
     DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2;
     int tiles = 0;
 
@@ -348,7 +350,16 @@ struct rcfm_demod_s {
             eng_A = std::make_unique<FftEngine>(A);
             buf_T.reset(c * eng_B->tmp_stride() * sizeof(float2));
             buf_TA.reset(c * eng_A->tmp_stride() * sizeof(float2));
-            if (kind == RCFM_WBFM) buf_U2.reset(((c + 1) / 2) * B * sizeof(float2));
+            if (kind == RCFM_WBFM) {
+                buf_U2.reset(((c + 1) / 2) * B * sizeof(float2));
+                const FftPlanDesc& pd = eng_B->desc();
+                const char* off = std::getenv("RCFM_NO_TILE2");
+                if (pd.npass == 2 && !(off && off[0] == '1')) {
+                    const int64_t swapped[2] = {pd.pass[1].L, pd.pass[0].L};
+                    eng_Bi = std::make_unique<FftEngine>(B, swapped, 2);
+                    buf_Ti.reset(c * eng_Bi->tmp_stride() * sizeof(float2));
+                }
+            }
             if (kind != RCFM_WBFM) {
                 buf_Z.reset(c * B * sizeof(float2));   // full spectrum of the discriminator output
                 buf_V.reset(c * A * sizeof(float2));   // Hermitian audio spectrum
@@ -416,13 +427,25 @@ struct rcfm_demod_s {
                     StageTimer tm(ST_FFT_REAL_B, s);
                     fused_real_pair_fft(*eng_B, p, U2, T, cnt, s);
                 }
-                {   // one-sided mask -> inverse FFT -> 38 kHz carrier, L-R, stereo matrix (wbfm.py:83,86-87)
+                bool paired = false;
+                if (eng_Bi) {
+                    // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
+                    // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
                     StageTimer tm(ST_IFFT_B, s);
-                    fused_hilbert_pair_ifft_mix(*eng_B, U2, m, Z, T, cnt, s);
+                    paired = fused_hilbert_pair_ifft_mix_fft(*eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s);
                 }
-                {   // both stereo legs in one complex FFT; only |k| <= A/2 survives the decimation
+                if (paired) {
                     StageTimer tm(ST_FFT_B, s);
-                    fused_fft_pruned(*eng_B, Z, Z, T, cnt, std::min(A, B) / 2, s);
+                    fused_fft_last_pruned(*eng_B, T, Z, cnt, std::min(A, B) / 2, s);
+                } else {
+                    {   // one-sided mask -> inverse FFT -> 38 kHz carrier, L-R, stereo matrix (wbfm.py:83,86-87)
+                        StageTimer tm(ST_IFFT_B, s);
+                        fused_hilbert_pair_ifft_mix(*eng_B, U2, m, Z, T, cnt, s);
+                    }
+                    {   // both stereo legs in one complex FFT; only |k| <= A/2 survives the decimation
+                        StageTimer tm(ST_FFT_B, s);
+                        fused_fft_pruned(*eng_B, Z, Z, T, cnt, std::min(A, B) / 2, s);
+                    }
                 }
                 {
                     StageTimer tm(ST_AUDIO_SPECTRUM, s);

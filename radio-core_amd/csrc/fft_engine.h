@@ -58,7 +58,9 @@ struct FftPlanDesc {
 // another prime factor, is too small to tile, or does not fit 4 passes; callers then
 // fall back to rocFFT.
 // max_l (<= kFftMaxL, 0 = default) caps the per-pass length; tests use it to force deep plans.
-bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l = 0);
+// `forced` (nforced factors whose product is n) overrides the planner's choice of pass lengths.
+bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l = 0, const int64_t* forced = nullptr,
+                       int nforced = 0);
 
 // Device-side view of one pass, handed to the kernel by value.
 struct FftPassDev {
@@ -75,6 +77,9 @@ struct FftPassDev {
 class FftEngine {
    public:
     explicit FftEngine(int64_t n);
+    // Same transform with the pass lengths given (e.g. the planner's two factors swapped, so that
+    // this plan's last pass tiles exactly like another plan's first pass: fused_passes.h).
+    FftEngine(int64_t n, const int64_t* factors, int nfactors);
     const FftPlanDesc& desc() const { return desc_; }
     int npass() const { return desc_.npass; }
     int64_t tmp_stride() const { return desc_.tmp_stride; }   // scratch elements per signal (>= n)
@@ -89,6 +94,7 @@ class FftEngine {
     static int compute_units();   // CUs of the current device (256 on MI355X)
 
    private:
+    void build_tables();
     FftPlanDesc desc_;
     DeviceBuffer stage_tw_[kFftMaxPasses];
     DeviceBuffer pos_[kFftMaxPasses];

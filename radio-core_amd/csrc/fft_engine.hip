@@ -104,15 +104,27 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
 
 }  // namespace
 
-bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l) {
+bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* forced, int nforced) {
     if (max_l <= 0 || max_l > kFftMaxL) max_l = kFftMaxL;
     if (n < 256 || n >= (int64_t(1) << 32) || !smooth235(n)) return false;
     int np = 0;
     int64_t f[kFftMaxPasses];
-    for (int cand = 2; cand <= kFftMaxPasses; ++cand) {
-        if (split(n, cand, max_l, f)) {
-            np = cand;
-            break;
+    if (forced != nullptr) {
+        if (nforced < 2 || nforced > kFftMaxPasses) return false;
+        int64_t prod = 1;
+        for (int i = 0; i < nforced; ++i) {
+            if (forced[i] < 16 || forced[i] > kFftMaxL) return false;
+            f[i] = forced[i];
+            prod *= forced[i];
+        }
+        if (prod != n) return false;
+        np = nforced;
+    } else {
+        for (int cand = 2; cand <= kFftMaxPasses; ++cand) {
+            if (split(n, cand, max_l, f)) {
+                np = cand;
+                break;
+            }
         }
     }
     if (!np) return false;
@@ -202,6 +214,17 @@ int FftEngine::compute_units() {
 
 FftEngine::FftEngine(int64_t n) {
     RC_REQUIRE(fft_plan_describe(n, &desc_), RCFM_ERR_ARG, "length not supported by the FFT engine");
+    build_tables();
+}
+
+FftEngine::FftEngine(int64_t n, const int64_t* factors, int nfactors) {
+    RC_REQUIRE(fft_plan_describe(n, &desc_, 0, factors, nfactors), RCFM_ERR_ARG,
+               "pass lengths not supported by the FFT engine");
+    build_tables();
+}
+
+void FftEngine::build_tables() {
+    const int64_t n = desc_.n;
     for (int t = 0; t < desc_.npass; ++t) {
         const FftPass& p = desc_.pass[t];
         std::vector<float2> tw(p.L);

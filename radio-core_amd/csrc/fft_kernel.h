@@ -576,6 +576,176 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     }
 }
 
+// ---- two transforms on one tile -----------------------------------------------------
+//
+// When plan P1 = (n_2, n_1) ends where plan P2 = (n_1, n_2) begins, the last (rows) pass of P1
+// and the first (strided) pass of P2 own the SAME tile: output k of line j of the first is
+// input l = k of line j of the second (both are point j + n_2 k of the natural-order signal).
+// This kernel runs both length-L transforms back to back with a point-wise stage in between
+// (MidOp, natural order), so the signal between them never travels to memory: one read and
+// one write instead of two of each.  Used for ifft -> stereo mix -> fft in WBFM.
+//
+// MidOp contract: kAux + fetch_aux(id, k, base, off) like StoreOp; float2 operator()(id, k, v, aux).
+template <int L, int R0, int R1, int R2, int R3, int T, class LoadOp, class MidOp, class StoreOp>
+__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev d1, FftPassDev d2, LoadOp load,
+                                                                     MidOp mid, StoreOp store) {
+    constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
+    constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;
+    constexpr int RG = T / W;
+    constexpr int nld = (L * W + T - 1) / T;
+    constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
+    __shared__ __attribute__((aligned(16))) float2 tile[L * W];
+    __shared__ __attribute__((aligned(16))) float2 tw[L];
+    const FftPass& p1 = d1.p;
+    const FftPass& p2 = d2.p;
+    const int tid = threadIdx.x;
+    const int w = tid & (W - 1), rg = tid >> 4;
+
+    LineId id;
+    id.batch = blockIdx.z;
+    id.o1 = 0;
+    id.o2 = 0;
+    const int i0 = blockIdx.x * W;
+    const int left = (int)p1.n_inner - i0;
+    const int wvalid = left < W ? left : W;
+    const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
+    const int64_t mid_base = (int64_t)id.batch * d1.out_batch + i0;      // natural-order signal
+    const int64_t out_base = (int64_t)id.batch * d2.out_batch + i0;
+    const unsigned in_i = (unsigned)p1.in_i, mid_k = (unsigned)p1.out_k, out_k = (unsigned)p2.out_k;
+
+    auto kbase = [](int g) -> int {
+        if constexpr (S == 2) {
+            return g;
+        } else if constexpr (S == 3) {
+            constexpr int w1 = L / (R0 * RL);
+            const int q1 = g / w1, q2 = g - q1 * w1;
+            return q1 + R0 * q2;
+        } else {
+            constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
+            const int q1 = g / w1, r1 = g - q1 * w1;
+            const int q2 = r1 / w2, q3 = r1 - q2 * w2;
+            return q1 + R0 * (q2 + R1 * q3);
+        }
+    };
+
+    // ---- loads of the first transform (contiguous lines) + the mid stage's inputs ----------
+    float2 v[nld];
+#pragma unroll
+    for (int it = 0; it < nld; ++it) {
+        int e = tid + T * it;
+        if ((L * W) % T != 0) e = e < L * W ? e : 0;
+        const int wl = e / L, l = e - wl * L;
+        const int wc = wl < wvalid ? wl : 0;
+        id.i = i0 + wc;
+        v[it] = load.fetch(id, l, in_base, (unsigned)wc * in_i + (unsigned)l);
+    }
+    float aux[nitL * RL];
+    {
+        const int wc = w < wvalid ? w : 0;
+        id.i = i0 + wc;
+#pragma unroll
+        for (int it = 0; it < nitL; ++it) {
+            int g = rg + RG * it;
+            if (rowsL % RG != 0) g = g < rowsL ? g : 0;
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const int k = kb + (L / RL) * q;
+                aux[it * RL + q] = mid.fetch_aux(id, k, mid_base, (unsigned)k * mid_k + (unsigned)wc);
+            }
+        }
+    }
+    for (int e = tid; e < L; e += T) tw[e] = d1.stage_tw[e];
+
+#pragma unroll
+    for (int it = 0; it < nld; ++it) {
+        const int e = tid + T * it;
+        const int wl = e / L, l = e - wl * L;
+        id.i = i0 + wl;
+        float2 x = load.post(id, l, v[it]);
+        if (wl >= wvalid) x = make_float2(0.f, 0.f);
+        if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
+    }
+    __syncthreads();
+    stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+    __syncthreads();
+    if constexpr (S >= 3) {
+        stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+    if constexpr (S >= 4) {
+        stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+
+    // ---- last stage of the first transform: results leave their digit-reversed slots, pass the
+    // mid stage, and land in natural order (row k) for the second transform -----------------
+    id.i = i0 + w;
+    float2 xr[nitL * RL];
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+#pragma unroll
+            for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
+            dft_p<RL>(&xr[it * RL]);
+        }
+    }
+    __syncthreads();   // every slot has been read
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const int k = kb + (L / RL) * q;
+                float2 y = mid(id, k, xr[it * RL + dft_slot<RL>(q)], aux[it * RL + q]);
+                if (w >= wvalid) y = make_float2(0.f, 0.f);
+                tile[lds_slot<true>(k, w)] = y;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- second transform: a strided pass of plan 2 whose input already sits in LDS ----------
+    stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+    __syncthreads();
+    if constexpr (S >= 3) {
+        stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+    if constexpr (S >= 4) {
+        stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+    const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
+    const float2 D = big_twiddle(d2, f * (unsigned)(L / RL));
+    const bool lane_ok = w < wvalid;
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            float2 x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
+            dft_p<RL>(x);
+            const int kb = kbase(g);
+            float2 Tw = big_twiddle(d2, f * (unsigned)kb);
+            if (lane_ok) {
+#pragma unroll
+                for (int q = 0; q < RL; ++q) {
+                    const int k = kb + (L / RL) * q;
+                    const float2 y = cmul(x[dft_slot<RL>(q)], Tw);
+                    Tw = cmul(Tw, D);
+                    store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
+                }
+            }
+        }
+    }
+}
+
 // ---- plain functors ------------------------------------------------------------
 // SWAP = exchange re/im: the inverse transform by the swap identity ifft(x) = swap(fft(swap(x))).
 
@@ -667,6 +837,30 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
         hipLaunchKernelGGL((k_fft_pass<LoadOp, StoreOp>), FftEngine::grid(d.p, batch), dim3(kThreads),
                            FftEngine::lds_bytes(d.p.L), s, d, ld, st);
     RC_HIP(hipGetLastError());
+}
+
+// d1: last pass of plan (n_2, n_1); d2: first pass of plan (n_1, n_2).  Returns false when the
+// pair does not tile identically or the length has no specialisation (caller runs them apart).
+template <class LoadOp, class MidOp, class StoreOp>
+inline bool launch_fft_tile2(const FftPassDev& d1, const FftPassDev& d2, int batch, const LoadOp& ld,
+                             const MidOp& mid, const StoreOp& st, hipStream_t s) {
+    const bool ok = d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L && d1.p.n_inner == d2.p.n_inner &&
+                    d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 && d1.p.out_k == d2.p.in_l &&
+                    d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
+    if (!ok || getenv_generic_fft()) return false;
+    const dim3 grid((unsigned)((d1.p.n_inner + W - 1) / W), 1, (unsigned)batch);
+    switch (d1.p.L) {
+#define RCFM_CASE(LEN, A, B, C, D)                                                                           \
+    case LEN:                                                                                                \
+        hipLaunchKernelGGL((k_fft_tile2<LEN, A, B, C, D, tile_threads(LEN), LoadOp, MidOp, StoreOp>), grid,  \
+                           dim3(tile_threads(LEN)), 0, s, d1, d2, ld, mid, st);                              \
+        break;
+        RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+#undef RCFM_CASE
+        default: return false;
+    }
+    RC_HIP(hipGetLastError());
+    return true;
 }
 
 }  // namespace fftk

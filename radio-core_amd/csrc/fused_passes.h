@@ -38,6 +38,16 @@ void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2*
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const float* m, float2* u, float2* tmp,
                                  int count, hipStream_t s);
 
+// Analytic-signal IFFT, stereo mix and the FIRST pass of the packed L/R FFT in two launches:
+// `ei` is the plan of length n with its two pass lengths swapped relative to `ef`, so ei's last
+// pass and ef's first pass own the same tiles and run as one kernel (k_fft_tile2); the mixed
+// signal u never reaches memory.  Leaves ef's scratch (tmp_f) ready for fused_fft_last_pruned.
+// Returns false (nothing launched) when the two plans do not pair up.
+bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* m,
+                                     float2* tmp_i, float2* tmp_f, int count, hipStream_t s);
+void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,
+                           hipStream_t s);
+
 // Forward FFT whose last pass stores only the bins |k| <= keep (decimation to A needs no more).
 void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,
                       hipStream_t s);

@@ -166,6 +166,22 @@ struct StoreStereoMix {
     }
 };
 
+// The same mix as the point-wise stage between two transforms (k_fft_tile2).
+struct MidStereoMix {
+    static constexpr bool kAux = true;
+    const float* m;
+    __device__ __forceinline__ float fetch_aux(const LineId&, int, int64_t base, unsigned off) const {
+        return (m + base)[off];
+    }
+    __device__ __forceinline__ float2 operator()(const LineId&, int, float2 v, float mm) const {
+        const float inv = __frcp_rn(fmaxf(fabsf(v.x), fabsf(v.y)));
+        const float za = v.y * inv, zb = v.x * inv;           // z = (v.y, v.x): swap identity
+        const float s2 = (2.f * za * zb) * __frcp_rn(za * za + zb * zb);
+        const float lmr = (s2 * mm) * 1.0175f;
+        return make_float2(mm + lmr, mm - lmr);
+    }
+};
+
 struct StorePruned {
     float2* out;
     int n, keep;
@@ -274,6 +290,35 @@ void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U, const floa
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StoreStereoMix stl{m, u};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
+}
+
+bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U, const float* m,
+                                     float2* tmp_i, float2* tmp_f, int count, hipStream_t s) {
+    if (count <= 0) return true;
+    if (ei.npass() != 2 || ef.npass() != 2 || ei.desc().n != ef.desc().n) return false;
+    const int64_t n = ei.desc().n;
+    const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);
+    const FftPassDev d2 = ef.pass_dev(0, n, ef.tmp_stride());
+    // would the pair tile identically?  (checked again by the launcher; test before running pass 0)
+    if (!(d1.p.L == d2.p.L && d1.p.n_inner == d2.p.n_inner && d1.p.out_k == d2.p.in_l)) return false;
+    LoadHilbertPair ld{U, (int)n, ei.desc().pass[0].in_l};
+    fftk::StorePlainT<false> st0{tmp_i, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(ei.pass_dev(0, 0, ei.tmp_stride()), count, ld, st0, s);
+    fftk::LoadPlainT<false> ldl{tmp_i};
+    MidStereoMix mid{m};
+    fftk::StorePlainT<false> st1{tmp_f, 1.0f};
+    RC_REQUIRE(fftk::launch_fft_tile2(d1, d2, count, ldl, mid, st1, s), RCFM_ERR_RUNTIME,
+               "two-transform tile kernel refused a pair it should accept");
+    return true;
+}
+
+void fused_fft_last_pruned(const FftEngine& e, const float2* tmp, float2* out, int count, int keep, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    fftk::LoadPlainT<false> ldl{tmp};
+    StorePruned stl{out, (int)n, keep};
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
