@@ -324,7 +324,7 @@ struct rcfm_demod_s {
     std::unique_ptr<FftEngine> eng_B, eng_A;   // both set: the engine path with fused passes
     std::unique_ptr<FftEngine> eng_Bi;         // eng_B's two pass lengths swapped (k_fft_tile2 pairing)
     DeviceBuffer buf_Ti;
-    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2;
+    DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2, buf_dc;
     int tiles = 0;
 
     void alloc() {
@@ -344,6 +344,7 @@ struct rcfm_demod_s {
             if (kind == RCFM_MFM) buf_v.reset(c * A * sizeof(float));
         }
         if (kind != RCFM_FM) partial.reset((size_t)chunk * ch * tiles * sizeof(float));
+        buf_dc.reset((size_t)chunk * sizeof(float2));
         FftPlanDesc probe;
         if (use_engine() && fft_plan_describe(B, &probe) && fft_plan_describe(A, &probe)) {
             eng_B = std::make_unique<FftEngine>(B);
@@ -376,12 +377,22 @@ struct rcfm_demod_s {
     }
 
     // mfm.py:63-65 / wbfm.py:90-100: de-emphasis (per-leg state), joint DC removal, clip.
-    void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s) {
+    void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s, bool have_dc = false) {
         const bool fast = ((int64_t)A * ch) % 4 == 0;
+        if (fast && have_dc && A >= 50) {
+            // de-emphasis, DC removal and clip in one kernel: the mean comes from the DC bin (buf_dc)
+            {
+                StageTimer tm(ST_DEEMPH, s);
+                launch_fir51(v, audio, A, ch, cnt, taps_h, st, nullptr, buf_dc.as<float2>(), s);
+            }
+            StageTimer tm(ST_DEEMPH_STATE, s);
+            launch_fir_state(v, A, ch, cnt, taps.as<float>(), 51, st, s);
+            return;
+        }
         {
             StageTimer tm(ST_DEEMPH, s);
             if (fast)
-                launch_fir51(v, audio, A, ch, cnt, taps_h, st, partial.as<float>(), s);
+                launch_fir51(v, audio, A, ch, cnt, taps_h, st, partial.as<float>(), nullptr, s);
             else
                 launch_fir(v, audio, A, ch, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
         }
@@ -450,14 +461,14 @@ struct rcfm_demod_s {
                 {
                     StageTimer tm(ST_AUDIO_SPECTRUM, s);
                     launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
-                                         geom.nyq_factor, geom.scale, s);
+                                         geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
                 }
                 {
                     StageTimer tm(ST_IFFT_A, s);
                     eng_A->c2c(V, V, TA, cnt, true, 1.0f, s);   // -> [cnt][A][2] float32, L/R interleaved
                 }
                 float* st = state.as<float>() + (size_t)first * ch * 50;
-                run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s);
+                run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true);
                 return;
             }
             // wbfm.py:80 / pll.py:34  analytic signal of the pilot
@@ -485,7 +496,7 @@ struct rcfm_demod_s {
             {
                 StageTimer tm(ST_AUDIO_SPECTRUM, s);
                 launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
-                                     geom.nyq_factor, geom.scale, s);
+                                     geom.nyq_factor, geom.scale, nullptr, s);
             }
             {
                 StageTimer tm(ST_IFFT_A, s);
@@ -524,7 +535,7 @@ struct rcfm_demod_s {
             {
                 StageTimer tm(ST_AUDIO_SPECTRUM, s);
                 launch_spectrum_real_full(Dfull, B, Yfull, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
-                                          geom.nyq_factor, geom.scale, s);
+                                          geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
             }
             float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
             {
@@ -533,7 +544,7 @@ struct rcfm_demod_s {
             }
             if (kind == RCFM_FM) return;
             float* st = state.as<float>() + (size_t)first * 50;
-            run_deemph(dst, audio, st, cnt, s);
+            run_deemph(dst, audio, st, cnt, s, true);
             return;
         }
         FftPlan& f1 = r2c_B.get(FftKind::R2C, B, cnt, false, need);

@@ -27,8 +27,10 @@ void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int b
 
 // Same resampling rule, but from the FULL complex spectrum X [batch][n] of a real signal to
 // the full Hermitian spectrum Y [batch][m] (feeds a complex inverse FFT whose real part is y).
+// dc (optional, [batch]): receives Y[c][0], the DC bin (sum of the resampled signal / m).
 void launch_spectrum_real_full(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
-                               int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream);
+                               int nyq, int nmin, float nyq_factor, float scale, float2* dc,
+                               hipStream_t stream);
 
 // scipy.signal.hilbert's mask (pll.py:34): P [batch][n/2+1] half spectrum of the real
 // input -> Z [batch][n] one-sided spectrum {1, 2, ..., 2, 1, 0, ...} * scale.
@@ -38,8 +40,9 @@ void launch_hilbert_mask(const float2* P, float2* Z, int64_t n, int batch, float
 // WBFM audio decimation of both stereo legs at once (wbfm.py:86-87): U = FFT_B of the
 // packed signal (m+lmr) + j(m-lmr); V [batch][A] = packed spectrum whose inverse FFT is
 // l + j r, with the Hamming weight, truncation and Nyquist rule of decimate.py:48.
+// dc (optional, [batch]): receives V[c][0] = (sum l, sum r) / A.
 void launch_stereo_unpack(const float2* U, int64_t B, float2* V, int64_t A, int batch, const float* wr,
-                          int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream);
+                          int nyq, int nmin, float nyq_factor, float scale, float2* dc, hipStream_t stream);
 
 // fm.py:60-65: d[0] = 0, d[i] = arg(x[i] conj(x[i-1])) / pi.
 void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipStream_t stream);
@@ -73,8 +76,10 @@ void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const fl
 // The 51-tap de-emphasis case, register-blocked (n*ch % 4 == 0 for its 16-byte stores);
 // partial: [batch][fir51_tiles(n, ch)] (both stereo legs share a tile).  taps_host: 51 floats.
 int fir51_tiles(int64_t n, int ch);
+// dc != nullptr ([batch], from launch_stereo_unpack / launch_spectrum_real_full): the kernel also
+// removes the mean and clips (mfm.py:64-65, wbfm.py:97-100); `partial` is then unused.  Needs n >= 50.
 void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const float* taps_host,
-                  const float* state, float* partial, hipStream_t stream);
+                  const float* state, float* partial, const float2* dc, hipStream_t stream);
 // Advance `state` to the end of the buffer (must run after launch_fir on the stream).
 void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
                       float* state, hipStream_t stream);

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(kThreads) void k_spectrum_r2c(const float2* __restr
 __global__ __launch_bounds__(kThreads) void k_spectrum_real_full(const float2* __restrict__ X, int64_t n,
                                                                  float2* __restrict__ Y, int64_t m,
                                                                  const float* __restrict__ wr, int nyq, int nmin,
-                                                                 float nyq_factor, float scale) {
+                                                                 float nyq_factor, float scale,
+                                                                 float2* __restrict__ dc) {
     const int c = blockIdx.y;
     const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (k >= m) return;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(kThreads) void k_spectrum_real_full(const float2* _
     }
     if (mirrored) y.y = -y.y;
     Y[(int64_t)c * m + k] = y;
+    if (k == 0 && dc != nullptr) dc[c] = y;
 }
 
 __global__ __launch_bounds__(kThreads) void k_hilbert_mask(const float2* __restrict__ P,
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(kThreads) void k_hilbert_mask(const float2* __restr
 __global__ __launch_bounds__(kThreads) void k_stereo_unpack(const float2* __restrict__ U, int64_t B,
                                                             float2* __restrict__ V, int64_t A,
                                                             const float* __restrict__ wr, int nyq, int nmin,
-                                                            float nyq_factor, float scale) {
+                                                            float nyq_factor, float scale,
+                                                            float2* __restrict__ dc) {
     const int c = blockIdx.y;
     const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (k >= A) return;
@@ -146,7 +149,9 @@ __global__ __launch_bounds__(kThreads) void k_stereo_unpack(const float2* __rest
         hr.y = -hr.y;
     }
     // packed Hermitian pair: V = HL + j HR  ->  ifft(V) = l + j r
-    V[(int64_t)c * A + k] = make_float2(hl.x - hr.y, hl.y + hr.x);
+    const float2 out = make_float2(hl.x - hr.y, hl.y + hr.x);
+    V[(int64_t)c * A + k] = out;
+    if (k == 0 && dc != nullptr) dc[c] = out;   // sum_n l[n] = A Re V[0], sum_n r[n] = A Im V[0]
 }
 
 // ---------------------------------------------------------------------------
@@ -445,15 +450,22 @@ struct DeemphTaps {
 constexpr int kFirPer = 8;
 constexpr int kFirFastTile = kThreads * kFirPer;   // 2048 interleaved outputs per workgroup
 
+// dc != nullptr: the DC removal and clip of mfm.py:64-65 / wbfm.py:97-100 happen here as well.
+// The mean of the filter OUTPUT follows from sums the pipeline already has:
+//   sum_n y_h[n] = sum_j b[j] (S_h - tail_h(j)) + sum_{n<50} z_h[n],
+// S_h = sum of the leg's input = A * (DC bin of its spectrum, dc[c]), tail_h(j) = sum of its last j
+// inputs, z = the carried filter state: 150 values per workgroup instead of a pass over the audio.
 template <int CH>
 __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x, float* __restrict__ y,
                                                     int64_t total, DeemphTaps taps,
                                                     const float* __restrict__ state,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ partial,
+                                                    const float2* __restrict__ dc) {
     constexpr int T = kFirFastTile, PER = kFirPer, HIST = 50 * CH;
     constexpr int NW = (PER + HIST + 3) / 4;                       // float4 reads per thread
     __shared__ __attribute__((aligned(16))) float x_s[T + NW * 4];  // z[t0 - HIST + s]
     __shared__ float red[kThreads / 64];
+    __shared__ float tail_s[HIST], z_s[HIST], leg_s[CH];
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * T;
@@ -461,6 +473,11 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
     float* yc = y + (int64_t)c * total;
     constexpr int NL = (T + HIST + kThreads - 1) / kThreads;
     float v[NL];
+    float tail_v = 0.f, z_v = 0.f;
+    if (dc != nullptr && tid < HIST) {                              // last 50 inputs of each leg + state
+        tail_v = xc[total - 1 - tid];                               // interleaved: leg = (total-1-tid) % CH
+        z_v = state[(int64_t)c * HIST + tid];
+    }
 #pragma unroll
     for (int it = 0; it < NL; ++it) {                              // unconditional, clamped loads
         const int64_t e = t0 - HIST + tid + kThreads * it;
@@ -472,7 +489,31 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         const int64_t e = t0 - HIST + s;
         if (s < T + NW * 4) x_s[s] = (e >= 0 && e < total) ? v[it] : 0.f;
     }
+    if (dc != nullptr && tid < HIST) {
+        tail_s[tid] = tail_v;
+        z_s[tid] = z_v;
+    }
     __syncthreads();
+    float mean = 0.f;
+    if (dc != nullptr) {
+        if (tid < CH) {
+            // leg h = tid: its samples from the end are xc[total-1-(CH*i + (CH-1-h))], i = 0..49
+            const int A = (int)(total / CH);
+            const float2 d0 = dc[c];
+            const float S = (float)A * (tid == 0 ? d0.x : d0.y);
+            float acc = taps.b[0] * S, tl = 0.f, zsum = 0.f;
+            for (int j = 1; j <= 50; ++j) {
+                tl += tail_s[CH * (j - 1) + (CH - 1 - tid)];
+                acc = fmaf(taps.b[j], S - tl, acc);
+            }
+            for (int i = 0; i < 50; ++i) zsum += z_s[tid * 50 + i];
+            leg_s[tid] = acc + zsum;
+        }
+        __syncthreads();
+        float tot = 0.f;
+        for (int h = 0; h < CH; ++h) tot += leg_s[h];
+        mean = tot / (float)total;
+    }
     const int o = tid * PER;
     float w[NW * 4];
 #pragma unroll
@@ -499,6 +540,13 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         for (int r = 0; r < PER; ++r) {
             const int64_t e = e0 + r;
             if (e < HIST && e < total) acc[r] += state[(int64_t)c * HIST + (e % CH) * 50 + e / CH];
+        }
+    }
+    if (dc != nullptr) {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const float t = acc[r] - mean;
+            acc[r] = (t < -0.999f) ? -0.999f : ((t > 0.999f) ? 0.999f : t);   // NaN stays NaN like np.clip
         }
     }
     if (e0 + PER <= total) {
@@ -585,10 +633,11 @@ void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int b
 }
 
 void launch_spectrum_real_full(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
-                               int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream) {
+                               int nyq, int nmin, float nyq_factor, float scale, float2* dc,
+                               hipStream_t stream) {
     if (batch <= 0) return;
     hipLaunchKernelGGL(k_spectrum_real_full, grid2(m, kThreads, batch), dim3(kThreads), 0, stream, X, n, Y, m,
-                       wr, nyq, nmin, nyq_factor, scale);
+                       wr, nyq, nmin, nyq_factor, scale, dc);
     RC_LAUNCH_CHECK();
 }
 
@@ -600,10 +649,10 @@ void launch_hilbert_mask(const float2* P, float2* Z, int64_t n, int batch, float
 }
 
 void launch_stereo_unpack(const float2* U, int64_t B, float2* V, int64_t A, int batch, const float* wr,
-                          int nyq, int nmin, float nyq_factor, float scale, hipStream_t stream) {
+                          int nyq, int nmin, float nyq_factor, float scale, float2* dc, hipStream_t stream) {
     if (batch <= 0) return;
     hipLaunchKernelGGL(k_stereo_unpack, grid2(A, kThreads, batch), dim3(kThreads), 0, stream, U, B, V, A, wr,
-                       nyq, nmin, nyq_factor, scale);
+                       nyq, nmin, nyq_factor, scale, dc);
     RC_LAUNCH_CHECK();
 }
 
@@ -663,15 +712,15 @@ void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const fl
 int fir51_tiles(int64_t n, int ch) { return (int)((n * ch + kFirFastTile - 1) / kFirFastTile); }
 
 void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const float* taps_host,
-                  const float* state, float* partial, hipStream_t stream) {
+                  const float* state, float* partial, const float2* dc, hipStream_t stream) {
     if (batch <= 0 || n <= 0) return;
     DeemphTaps taps;
     for (int i = 0; i < 51; ++i) taps.b[i] = taps_host[i];
     const dim3 grid((unsigned)fir51_tiles(n, ch), (unsigned)batch, 1);
     if (ch == 2)
-        hipLaunchKernelGGL(k_fir51<2>, grid, dim3(kThreads), 0, stream, x, y, n * 2, taps, state, partial);
+        hipLaunchKernelGGL(k_fir51<2>, grid, dim3(kThreads), 0, stream, x, y, n * 2, taps, state, partial, dc);
     else
-        hipLaunchKernelGGL(k_fir51<1>, grid, dim3(kThreads), 0, stream, x, y, n, taps, state, partial);
+        hipLaunchKernelGGL(k_fir51<1>, grid, dim3(kThreads), 0, stream, x, y, n, taps, state, partial, dc);
     RC_LAUNCH_CHECK();
 }
 
