@@ -283,6 +283,17 @@ def main():
     achieved = alg_bytes / per_launch_s if per_launch_s else 0.0
     total_alg = 16.0 * N + mine * (path_bytes(N, C, B, A, kind) - 16.0 * N) / C
 
+    # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (FETCH_SIZE x its
+    # gfx950 correction + WRITE_SIZE, collected separately; profiles/r01_e_pmc_hbm_traffic.txt)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            entry = json.load(fh).get(dominant)
+        if entry and args.config == "cfg4":
+            traffic = float(entry["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
+
     result = {
         "metric": "IQ Msamples/s through Tuner+%s at %d channels" % (kind, C),
         "value": round(value, 2),
@@ -307,7 +318,7 @@ def main():
         "path_algorithmic_GB": round(total_alg / 1e9, 3),
         "roofline": {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
             "launch_us": round(per_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": alg_bytes,
             "share_of_step": round(dom[1] / args.steps / ms_per_step, 3),
