@@ -223,3 +223,28 @@ def test_full_size_channel_properties(rc, oracle):
     y1 = tuner.run(2)
     tuner.load(0.5 * x)
     assert rel_err(2.0 * tuner.run(2), y1) <= 1e-5
+
+
+def test_pinned_buffer_feeds_the_tuner(rc):
+    """Buffer(cuda=True) is page-locked host memory; loading the Tuner
+    from it gives the same channel as loading from an ordinary array."""
+    import torch
+    N, B = 600000, 60000
+    buf = rc.Buffer(N, dtype=np.complex64, cuda=True)
+    assert buf.is_cuda and buf.data.dtype == np.complex64 and len(buf) == N
+    assert torch.from_numpy(buf.data.view(np.float32)).is_pinned() or buf._owner.is_pinned()
+    x = workloads.wideband(N, 100e6, [100e6, 100.1e6], B, gain=0.5)
+    with buf.consume() as arr:
+        arr[:] = x
+    t = rc.Tuner()
+    t.add_channel(100e6, B, None)
+    t.add_channel(100.1e6, B, None)
+    t.request_bandwidth(float(N))
+    t.load(buf.data)
+    a = t.run(1)
+    t.load(x)
+    assert np.array_equal(a, t.run(1))
+    ring = rc.RingBuffer(N, dtype=np.complex64, cuda=True)
+    ring.put(x)
+    out = np.zeros(N, np.complex64)
+    assert ring.get(out) is True and np.array_equal(out, x)
