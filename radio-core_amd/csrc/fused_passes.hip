@@ -162,7 +162,7 @@ struct StoreStereoMix {
         const float za = v.y * inv, zb = v.x * inv;
         const float s2 = (2.f * za * zb) * __frcp_rn(za * za + zb * zb);
         const float lmr = (s2 * mm) * 1.0175f;
-        (u + base)[off] = make_float2(mm + lmr, mm - lmr);
+        fftk::stream_store(u + base + off, make_float2(mm + lmr, mm - lmr));
     }
 };
 
@@ -187,7 +187,7 @@ struct StorePruned {
     int n, keep;
     __device__ __forceinline__ void operator()(const LineId& id, int, int64_t base, unsigned off, float2 v) const {
         const int k = (int)(base + off - (int64_t)id.batch * n);
-        if (keep < 0 || k <= keep || k >= n - keep) (out + base)[off] = v;
+        if (keep < 0 || k <= keep || k >= n - keep) fftk::stream_store(out + base + off, v);
     }
 };
 

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "librcfm.so")
+LIB_PATH = os.environ.get("RCFM_LIB") or os.path.join(os.path.dirname(_HERE), "_lib", "librcfm.so")
 
 RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
 
