@@ -870,13 +870,25 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
 
 // d1: last pass of plan (n_2, n_1); d2: first pass of plan (n_1, n_2).  Returns false when the
 // pair does not tile identically or the length has no specialisation (caller runs them apart).
+inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int batch) {
+    bool fast = false;
+    switch (d1.p.L) {
+#define RCFM_CASE(LEN, A, B, C, D) case LEN:
+        RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+#undef RCFM_CASE
+        fast = true;
+        break;
+        default: break;
+    }
+    return fast && !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L &&
+           d1.p.n_inner == d2.p.n_inner && d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 &&
+           d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
+}
+
 template <class LoadOp, class MidOp, class StoreOp>
 inline bool launch_fft_tile2(const FftPassDev& d1, const FftPassDev& d2, int batch, const LoadOp& ld,
                              const MidOp& mid, const StoreOp& st, hipStream_t s) {
-    const bool ok = d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L && d1.p.n_inner == d2.p.n_inner &&
-                    d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 && d1.p.out_k == d2.p.in_l &&
-                    d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
-    if (!ok || getenv_generic_fft()) return false;
+    if (!fft_tile2_applies(d1, d2, batch)) return false;
     const dim3 grid((unsigned)((d1.p.n_inner + W - 1) / W), 1, (unsigned)batch);
     switch (d1.p.L) {
 #define RCFM_CASE(LEN, A, B, C, D)                                                                           \

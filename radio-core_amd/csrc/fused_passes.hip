@@ -300,8 +300,7 @@ bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, c
     const int64_t n = ei.desc().n;
     const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);
     const FftPassDev d2 = ef.pass_dev(0, n, ef.tmp_stride());
-    // would the pair tile identically?  (checked again by the launcher; test before running pass 0)
-    if (!(d1.p.L == d2.p.L && d1.p.n_inner == d2.p.n_inner && d1.p.out_k == d2.p.in_l)) return false;
+    if (!fftk::fft_tile2_applies(d1, d2, count)) return false;   // decided before anything is launched
     LoadHilbertPair ld{U, (int)n, ei.desc().pass[0].in_l};
     fftk::StorePlainT<false> st0{tmp_i, 1.0f};
     fftk::launch_fft_pass<kStridedOnly>(ei.pass_dev(0, 0, ei.tmp_stride()), count, ld, st0, s);
