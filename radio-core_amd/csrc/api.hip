@@ -728,11 +728,11 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
         d->tau = tau;
         d->ch = (kind == RCFM_WBFM) ? 2 : 1;
         if (chunk <= 0) {
-            // Measured on MI355X (profiles/r01_c_chunk_sweep.txt): bigger chunks win up to 256;
+            // Measured on MI355X (profiles/r01_c_chunk_sweep.txt): bigger chunks keep winning up to 512;
             // the kernels are tile-latency bound below ~64 channels per launch.
             const char* e = std::getenv("RCFM_CHUNK");
-            chunk = e ? std::atoi(e) : 256;
-            if (chunk <= 0) chunk = 256;
+            chunk = e ? std::atoi(e) : 512;
+            if (chunk <= 0) chunk = 512;
         }
         d->chunk = std::min(chunk, C);
         d->geom.build(B, A, 0.54 /* hamm */, false);
