@@ -436,7 +436,7 @@ struct rcfm_demod_s {
                 float2* U2 = buf_U2.as<float2>();
                 {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
                     StageTimer tm(ST_FFT_REAL_B, s);
-                    fused_real_pair_fft(*eng_B, p, U2, T, cnt, s);
+                    fused_real_pair_fft(*eng_B, p, U2, T, cnt, -1, s);
                 }
                 bool paired = false;
                 if (eng_Bi) {
@@ -530,12 +530,13 @@ struct rcfm_demod_s {
             float2* Yfull = buf_V.as<float2>();
             {
                 StageTimer tm(ST_FFT_REAL_B, s);
-                fused_real_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
+                // two channels per complex FFT; only |k| <= A/2 is kept (and read back by the unpacking)
+                fused_real_pair_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
             }
             {
                 StageTimer tm(ST_AUDIO_SPECTRUM, s);
                 launch_spectrum_real_full(Dfull, B, Yfull, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
-                                          geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
+                                          geom.nyq_factor, geom.scale, buf_dc.as<float2>(), true, s);
             }
             float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
             {

@@ -34,7 +34,9 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
 // The same two stages for real signals transformed two at a time: U2 [ceil(count/2)][n] =
 // FFT(x[2c] + j x[2c+1]); the Hilbert load of channel c unpacks its own spectrum from U2.
 // U2 must not alias u (u is written while other channels still read their pair).
-void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2* tmp, int count, hipStream_t s);
+// keep >= 0: only bins |k| <= keep of U2 are written.
+void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2* tmp, int count, int keep,
+                         hipStream_t s);
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const float* m, float2* u, float2* tmp,
                                  int count, hipStream_t s);
 

@@ -265,7 +265,8 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
-void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, hipStream_t s) {
+void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
+                         hipStream_t s) {
     if (count <= 0) return;
     const int64_t n = e.desc().n;
     const int np = e.npass();
@@ -275,8 +276,13 @@ void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* 
     fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, pairs, s);
     fftk::LoadPlainT<false> ldl{tmp};
-    fftk::StorePlainT<false> stl{U, 1.0f};
-    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), pairs, ldl, stl, s);
+    if (keep >= 0) {
+        StorePruned stl{U, (int)n, keep};
+        fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), pairs, ldl, stl, s);
+    } else {
+        fftk::StorePlainT<false> stl{U, 1.0f};
+        fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), pairs, ldl, stl, s);
+    }
 }
 
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,

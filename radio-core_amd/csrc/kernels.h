@@ -28,8 +28,9 @@ void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int b
 // Same resampling rule, but from the FULL complex spectrum X [batch][n] of a real signal to
 // the full Hermitian spectrum Y [batch][m] (feeds a complex inverse FFT whose real part is y).
 // dc (optional, [batch]): receives Y[c][0], the DC bin (sum of the resampled signal / m).
+// paired: X is [ceil(batch/2)][n], one complex FFT per pair of real signals (x[2p] + j x[2p+1]).
 void launch_spectrum_real_full(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
-                               int nyq, int nmin, float nyq_factor, float scale, float2* dc,
+                               int nyq, int nmin, float nyq_factor, float scale, float2* dc, bool paired,
                                hipStream_t stream);
 
 // scipy.signal.hilbert's mask (pll.py:34): P [batch][n/2+1] half spectrum of the real

@@ -81,11 +81,13 @@ __global__ __launch_bounds__(kThreads) void k_spectrum_r2c(const float2* __restr
     Y[(int64_t)c * mh + k] = cscale(y, scale);
 }
 
+// paired != 0: X holds FFT(x[2p] + j x[2p+1]) per pair p (two real signals per transform); channel c
+// takes X_c[k] = (U[k] + conj U[-k]) / 2 (even c) or (U[k] - conj U[-k]) / 2j (odd c).
 __global__ __launch_bounds__(kThreads) void k_spectrum_real_full(const float2* __restrict__ X, int64_t n,
                                                                  float2* __restrict__ Y, int64_t m,
                                                                  const float* __restrict__ wr, int nyq, int nmin,
                                                                  float nyq_factor, float scale,
-                                                                 float2* __restrict__ dc) {
+                                                                 float2* __restrict__ dc, int paired) {
     const int c = blockIdx.y;
     const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (k >= m) return;
@@ -93,7 +95,16 @@ __global__ __launch_bounds__(kThreads) void k_spectrum_real_full(const float2* _
     const int64_t kk = mirrored ? m - k : k;
     float2 y = make_float2(0.f, 0.f);
     if (kk < nyq) {
-        y = cscale(X[(int64_t)c * n + kk], wr[kk] * scale);
+        float2 xk;
+        if (paired) {
+            const float2* U = X + (int64_t)(c >> 1) * n;
+            const float2 a = U[kk], b = U[kk == 0 ? 0 : n - kk];
+            xk = (c & 1) ? make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x))
+                         : make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        } else {
+            xk = X[(int64_t)c * n + kk];
+        }
+        y = cscale(xk, wr[kk] * scale);
         if ((nmin & 1) == 0 && kk == nmin / 2) y = cscale(y, nyq_factor);
         if (kk == 0 || ((m & 1) == 0 && kk == m / 2)) y.y = 0.f;
     }
@@ -633,11 +644,11 @@ void launch_spectrum_r2c(const float2* X, int64_t n, float2* Y, int64_t m, int b
 }
 
 void launch_spectrum_real_full(const float2* X, int64_t n, float2* Y, int64_t m, int batch, const float* wr,
-                               int nyq, int nmin, float nyq_factor, float scale, float2* dc,
+                               int nyq, int nmin, float nyq_factor, float scale, float2* dc, bool paired,
                                hipStream_t stream) {
     if (batch <= 0) return;
     hipLaunchKernelGGL(k_spectrum_real_full, grid2(m, kThreads, batch), dim3(kThreads), 0, stream, X, n, Y, m,
-                       wr, nyq, nmin, nyq_factor, scale, dc);
+                       wr, nyq, nmin, nyq_factor, scale, dc, paired ? 1 : 0);
     RC_LAUNCH_CHECK();
 }
 
