@@ -365,8 +365,18 @@ __device__ __forceinline__ void dft_p(float2* v) {
     if constexpr (R == 10) dft10p(v);
 }
 
+// RCFM_FFT_ROWS_PITCH17 (default): rows-type tiles use a padded pitch of 17 points instead of the XOR
+// swizzle: constant LDS offsets instead of integer work per access; the transposing store stays
+// conflict-free (34-dword stride), 32-lane reads pay one extra LDS cycle.  Measured +1.4 % on cfg4
+// (the kernels are VALU-bound: SQ_ACTIVE_INST_VALU x waves per SIMD ~ 100 %, LDS far from busy).
+#ifndef RCFM_FFT_ROWS_PITCH17
+#define RCFM_FFT_ROWS_PITCH17 1
+#endif
+constexpr int kRowsPitch = RCFM_FFT_ROWS_PITCH17 ? W + 1 : W;
+
 template <bool SWZ>
 __device__ __forceinline__ int lds_slot(int row, int w) {
+    if (SWZ && RCFM_FFT_ROWS_PITCH17) return row * (W + 1) + w;
     return SWZ ? row * W + (w ^ (row & (W - 1))) : row * W + w;
 }
 
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     constexpr int RG = T / W;                                  // butterfly rows handled per sweep
     constexpr int nit0 = (m0 + RG - 1) / RG;                   // first-stage butterflies per thread
     constexpr int nld = ROWS ? (L * W + T - 1) / T : nit0 * R0;
-    __shared__ __attribute__((aligned(16))) float2 tile[L * W];
+    __shared__ __attribute__((aligned(16))) float2 tile[L * (ROWS ? kRowsPitch : W)];
     __shared__ __attribute__((aligned(16))) float2 tw[L];
     const FftPass& p = d.p;
     const int tid = threadIdx.x;
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
     constexpr int RG = T / W;
     constexpr int nld = (L * W + T - 1) / T;
     constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
-    __shared__ __attribute__((aligned(16))) float2 tile[L * W];
+    __shared__ __attribute__((aligned(16))) float2 tile[L * kRowsPitch];
     __shared__ __attribute__((aligned(16))) float2 tw[L];
     const FftPass& p1 = d1.p;
     const FftPass& p2 = d2.p;
