@@ -429,6 +429,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     const int i0 = blockIdx.x * W;
     const int left = (int)p.n_inner - i0;
     const int wvalid = left < W ? left : W;
+    const bool partial = wvalid < W;   // workgroup-uniform: only the last tile of a row masks lanes
     const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + (int64_t)i0 * p.in_i;
     const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0;
     const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
             float2 x;
             if constexpr (NF == 2) x = load.post(id, l, v[it], v2[it]);
             else x = load.post(id, l, v[it]);
-            if (wl >= wvalid) x = make_float2(0.f, 0.f);
+            if (partial && wl >= wvalid) x = make_float2(0.f, 0.f);
             if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
         }
         __syncthreads();
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
                 for (int q = 0; q < R0; ++q) {
                     if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
                     else x[q] = load.post(id, b + q * m0, x[q]);
-                    if (w >= wvalid) x[q] = make_float2(0.f, 0.f);
+                    if (partial && w >= wvalid) x[q] = make_float2(0.f, 0.f);
                 }
                 dft_p<R0>(x);
 #pragma unroll
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
     const int i0 = blockIdx.x * W;
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
+    const bool partial = wvalid < W;   // workgroup-uniform: only the last tile of a row masks lanes
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
     const int64_t mid_base = (int64_t)id.batch * d1.out_batch + i0;      // natural-order signal
     const int64_t out_base = (int64_t)id.batch * d2.out_batch + i0;
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
             for (int q = 0; q < RL; ++q) {
                 const int k = kb + (L / RL) * q;
                 float2 y = mid(id, k, xr[it * RL + dft_slot<RL>(q)], aux[it * RL + q]);
-                if (w >= wvalid) y = make_float2(0.f, 0.f);
+                if (partial && w >= wvalid) y = make_float2(0.f, 0.f);
                 tile[lds_slot<true>(k, w)] = y;
             }
         }
