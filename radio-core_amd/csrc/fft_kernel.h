@@ -23,14 +23,52 @@ namespace fftk {
 constexpr int kThreads = 256;
 constexpr int W = kFftTileW;
 
+// Complex product.  RCFM_ASM_CMUL: two packed instructions whose op_sel / neg modifiers pick the
+// halves (a.x b, then a.y (-b.y, b.x) + ...) -- the compiler's own packing builds those operand
+// pairs with v_mov's (19 % of the tile kernel's VALU instructions).
+#ifndef RCFM_ASM_CMUL
+#define RCFM_ASM_CMUL 1
+#endif
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+#if RCFM_ASM_CMUL
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f A, B, D;
+    A.x = a.x; A.y = a.y; B.x = b.x; B.y = b.y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(D) : "v"(A), "v"(B));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(D) : "v"(A), "v"(B));
+    return make_float2(D.x, D.y);
+#else
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // multiply by -i / +i
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }
+// t + (-i) u and t + (+i) u in one packed add (half-swap and sign via op_sel / neg_hi / neg_lo).
+__device__ __forceinline__ float2 cadd_mi(float2 t, float2 u) {
+#if RCFM_ASM_CMUL
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f T, U, D;
+    T.x = t.x; T.y = t.y; U.x = u.x; U.y = u.y;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(D) : "v"(T), "v"(U));
+    return make_float2(D.x, D.y);
+#else
+    return make_float2(t.x + u.y, t.y - u.x);
+#endif
+}
+__device__ __forceinline__ float2 cadd_pi(float2 t, float2 u) {
+#if RCFM_ASM_CMUL
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f T, U, D;
+    T.x = t.x; T.y = t.y; U.x = u.x; U.y = u.y;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(D) : "v"(T), "v"(U));
+    return make_float2(D.x, D.y);
+#else
+    return make_float2(t.x - u.y, t.y + u.x);
+#endif
+}
 
 // ---- small forward DFTs, y[q'] = sum_q x[q] exp(-2 pi i q q' / R), in place --------
 
@@ -46,17 +84,17 @@ __device__ __forceinline__ void dft3(float2& x0, float2& x1, float2& x2) {
     const float2 t = make_float2(x0.x - 0.5f * s.x, x0.y - 0.5f * s.y);
     const float2 u = make_float2(0.86602540378443864676f * d.x, 0.86602540378443864676f * d.y);
     x0 = cadd(x0, s);
-    x1 = cadd(t, mul_mi(u));
-    x2 = cadd(t, mul_pi(u));
+    x1 = cadd_mi(t, u);
+    x2 = cadd_pi(t, u);
 }
 
 __device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
     const float2 a = cadd(x0, x2), b = csub(x0, x2);
-    const float2 c = cadd(x1, x3), d = mul_mi(csub(x1, x3));
+    const float2 c = cadd(x1, x3), e = csub(x1, x3);
     x0 = cadd(a, c);
-    x1 = cadd(b, d);
+    x1 = cadd_mi(b, e);
     x2 = csub(a, c);
-    x3 = csub(b, d);
+    x3 = cadd_pi(b, e);
 }
 
 __device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4) {
@@ -68,10 +106,10 @@ __device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2&
     const float2 u1 = make_float2(s1 * c.x + s2 * d.x, s1 * c.y + s2 * d.y);
     const float2 u2 = make_float2(s2 * c.x - s1 * d.x, s2 * c.y - s1 * d.y);
     x0 = cadd(x0, cadd(a, b));
-    x1 = cadd(t1, mul_mi(u1));
-    x4 = cadd(t1, mul_pi(u1));
-    x2 = cadd(t2, mul_mi(u2));
-    x3 = cadd(t2, mul_pi(u2));
+    x1 = cadd_mi(t1, u1);
+    x4 = cadd_pi(t1, u1);
+    x2 = cadd_mi(t2, u2);
+    x3 = cadd_pi(t2, u2);
 }
 
 // Composite radices: R = R1 * R2, input q = q1 R2 + q2, output q' = k1 + R1 k2:
