@@ -251,7 +251,10 @@ struct rcfm_tuner_s {
     std::vector<int64_t> roll;   // normalised to [0, n)
     std::vector<int32_t> bw;
     DeviceBuffer roll_dev;
-    DeviceBuffer X;
+    DeviceBuffer base_dev;   // int32 (n - roll) mod n per channel: start of the channel in the haloed spectrum
+    DeviceBuffer X;          // [halo | n bins | halo]: the halos repeat the far ends, so a channel's bins
+    int64_t halo = 0;        //   base + d, |d| <= B/2 + 1, need no wrap-around (fused_passes.h)
+    float2* spectrum() { return X.as<float2>() + halo; }
     DeviceBuffer work;
     std::unique_ptr<FftPlan> forward;          // rocFFT fallback for lengths outside the engine
     std::unique_ptr<FftEngine> forward_engine;
@@ -289,7 +292,8 @@ struct rcfm_tuner_s {
         if (bd.engine) {
             // gather + window ride on the first pass of the inverse FFT (fused_passes.h)
             band_tmp.reserve((size_t)count * bd.engine->tmp_stride() * sizeof(float2));
-            TunerGather tg{X.as<float2>(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode};
+            TunerGather tg{spectrum(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode,
+                           halo ? base_dev.as<int32_t>() + first : nullptr, halo};
             StageTimer tm(ST_TUNER_IFFT, s);
             fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s);
             return;
@@ -299,7 +303,7 @@ struct rcfm_tuner_s {
         work.reserve(need);
         {
             StageTimer tm(ST_TUNER_GATHER, s);
-            launch_spectrum_c2c(X.as<float2>(), 0, n, roll_dev.as<int64_t>() + first, out, B, count,
+            launch_spectrum_c2c(spectrum(), 0, n, roll_dev.as<int64_t>() + first, out, B, count,
                                 g.wpos.as<float>(), g.wneg.as<float>(), g.w_merge, g.nyq, g.nneg, g.nyq_mode,
                                 g.scale, s);
         }
@@ -666,7 +670,17 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
             t->roll[i] = r;
         }
         if (nch) t->roll_dev.upload(t->roll.data(), sizeof(int64_t) * nch);
-        t->X.reset(sizeof(float2) * (size_t)n);
+        // halo: whole 128-byte lines on both sides, wide enough for the widest channel
+        int64_t h = 0;
+        for (int i = 0; i < nch; ++i) h = std::max<int64_t>(h, bw_host[i] / 2 + 2);
+        h = (h + 15) / 16 * 16;
+        if (nch && h <= n && n + h < ((int64_t)1 << 31)) {
+            t->halo = h;
+            std::vector<int32_t> base(nch);
+            for (int i = 0; i < nch; ++i) base[i] = (int32_t)((n - t->roll[i]) % n);
+            t->base_dev.upload(base.data(), sizeof(int32_t) * nch);
+        }
+        t->X.reset(sizeof(float2) * (size_t)(n + 2 * t->halo));
         FftPlanDesc probe;
         if (use_engine() && fft_plan_describe(n, &probe)) {
             t->forward_engine = std::make_unique<FftEngine>(n);
@@ -685,11 +699,17 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
         {
             StageTimer tm(ST_TUNER_FFT, as_stream(stream));
             if (t->forward_engine) {
-                t->forward_engine->c2c(static_cast<const float2*>(x), t->X.as<float2>(), t->forward_tmp.as<float2>(),
+                t->forward_engine->c2c(static_cast<const float2*>(x), t->spectrum(), t->forward_tmp.as<float2>(),
                                        1, false, 1.0f, as_stream(stream));
             } else {
                 t->work.reserve(t->forward->work_bytes());
-                t->forward->exec(const_cast<void*>(x), t->X.get(), t->work.get(), as_stream(stream));
+                t->forward->exec(const_cast<void*>(x), t->spectrum(), t->work.get(), as_stream(stream));
+            }
+            if (t->halo) {
+                float2* X = t->spectrum();
+                const size_t hb = sizeof(float2) * (size_t)t->halo;
+                RC_HIP(hipMemcpyAsync(X - t->halo, X + t->n - t->halo, hb, hipMemcpyDeviceToDevice, as_stream(stream)));
+                RC_HIP(hipMemcpyAsync(X + t->n, X, hb, hipMemcpyDeviceToDevice, as_stream(stream)));
             }
         }
         t->loaded = true;
@@ -706,7 +726,7 @@ int rcfm_tuner_run(rcfm_tuner_t t, int first, int count, void* out, void* stream
 int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X) {
     return guarded([&] {
         RC_REQUIRE(t && X, RCFM_ERR_ARG, "NULL argument");
-        *X = t->X.get();
+        *X = t->spectrum();
     });
 }
 

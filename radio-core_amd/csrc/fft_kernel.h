@@ -233,10 +233,19 @@ struct fetch_count { static constexpr int value = 1; };
 template <class T>
 struct fetch_count<T, std::void_t<decltype(T::kFetches)>> { static constexpr int value = T::kFetches; };
 
+// A LoadOp of a strided pass may carry workgroup-uniform state (kCtx: Ctx prepare(id) is evaluated
+// once with the tile's loads, post(id, l, v, ctx) receives it).
+template <class T, class = void>
+struct has_ctx : std::false_type {};
+template <class T>
+struct has_ctx<T, std::void_t<decltype(T::kCtx)>> : std::true_type {};
+
 template <class LoadOp>
 __device__ __forceinline__ float2 load_now(const LoadOp& load, const LineId& id, int l, int64_t base, unsigned off) {
     if constexpr (fetch_count<LoadOp>::value == 2)
         return load.post(id, l, load.fetch(id, l, base, off), load.fetch2(id, l, base, off));
+    else if constexpr (has_ctx<LoadOp>::value)
+        return load.post(id, l, load.fetch(id, l, base, off), load.prepare(id));
     else
         return load.post(id, l, load.fetch(id, l, base, off));
 }
@@ -503,6 +512,12 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
         }
     }
     for (int e = tid; e < L; e += T) tw[e] = d.stage_tw[e];
+    constexpr bool CTX = has_ctx<LoadOp>::value;
+    static_assert(!CTX || (!ROWS && NF == 1), "load context: strided single-fetch passes only");
+    auto ctx = [&] {
+        if constexpr (CTX) return load.prepare(id);
+        else return 0;
+    }();
 
     // Output index of slot 0 of last-stage block g (see the last stage below).
     constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
         stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
     } else {
         __syncthreads();   // tw[] complete
-        id.i = i0 + w;
+        id.i = i0 + (w < wvalid ? w : 0);   // same LineId as the fetch: index work is shared (masked below)
 #pragma unroll
         for (int it = 0; it < nit0; ++it) {
             const int b = rg + RG * it;
@@ -566,6 +581,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
 #pragma unroll
                 for (int q = 0; q < R0; ++q) {
                     if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
+                    else if constexpr (CTX) x[q] = load.post(id, b + q * m0, x[q], ctx);
                     else x[q] = load.post(id, b + q * m0, x[q]);
                     if (partial && w >= wvalid) x[q] = make_float2(0.f, 0.f);
                 }

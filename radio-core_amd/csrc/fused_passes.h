@@ -16,6 +16,10 @@ struct TunerGather {
     const int64_t* roll;   // device, one entry per channel of the range, already in [0, N)
     double a0;
     int nyq, nneg, nyq_mode;
+    // Optional fast addressing: X carries `halo` repeated bins on both sides and base32[c] =
+    // (N - roll[c]) mod N, so source bin d (|d| <= halo) of channel c is X[base32[c] + d].
+    const int32_t* base32 = nullptr;
+    int64_t halo = 0;
 };
 void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
                       hipStream_t s);
