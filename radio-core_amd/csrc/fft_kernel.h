@@ -250,6 +250,15 @@ __device__ __forceinline__ float2 load_now(const LoadOp& load, const LineId& id,
         return load.post(id, l, load.fetch(id, l, base, off));
 }
 
+// A LoadOp of a strided pass whose input is zero above the middle of the signal (one-sided spectra:
+// point k = l * stride + i with n = L * stride, zero for k > n/2) declares kHalfZones = true.  The
+// kernel then tells fetch / fetch2 / post which zone the point's l lies in -- 0: l < L/2 for the
+// whole butterfly row, 1: mixed -- and neither loads nor post-processes zone 2 (l > L/2: zero).
+template <class T, class = void>
+struct has_half_zones : std::false_type {};
+template <class T>
+struct has_half_zones<T, std::void_t<decltype(T::kHalfZones)>> : std::bool_constant<T::kHalfZones> {};
+
 // A StoreOp may need one auxiliary input value per output point (kAux: fetch_aux(id, k, base, off)
 // is issued with the tile's loads, operator() receives the value as a sixth argument).
 template <class T, class = void>
@@ -475,14 +484,17 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     id.o2 = n_o2 == 1 ? 0 : o - (unsigned)id.o1 * n_o2;
     const int i0 = blockIdx.x * W;
     const int left = (int)p.n_inner - i0;
+    // Lanes past the end of a row (last tile only) load line 0 of the tile again and are never stored:
+    // every lane transforms its own line, so nothing has to be masked in between.
     const int wvalid = left < W ? left : W;
-    const bool partial = wvalid < W;   // workgroup-uniform: only the last tile of a row masks lanes
     const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + (int64_t)i0 * p.in_i;
     const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0;
     const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
 
     // ---- global loads: all issued before anything waits -----------------------------------
     constexpr int NF = fetch_count<LoadOp>::value;
+    constexpr bool HZ = !ROWS && has_half_zones<LoadOp>::value && L % 2 == 0;
+    auto zone = [](int q) -> int { return (q + 1) * m0 <= L / 2 ? 0 : (q * m0 > L / 2 ? 2 : 1); };
     float2 v[nld];
     float2 v2[NF == 2 ? nld : 1];
     if constexpr (ROWS) {
@@ -506,8 +518,21 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
 #pragma unroll
             for (int q = 0; q < R0; ++q) {
                 const int l = b + q * m0;
-                v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
-                if constexpr (NF == 2) v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
+                if constexpr (HZ) {
+                    static_assert(NF == 2, "half zones: two-fetch load functors");
+                    const int z = zone(q);
+                    if (z == 2) {
+                        v[it * R0 + q] = make_float2(0.f, 0.f);
+                        v2[it * R0 + q] = make_float2(0.f, 0.f);
+                    } else {
+                        v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc, z);
+                        v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc, z);
+                    }
+                } else {
+                    v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
+                    if constexpr (NF == 2)
+                        v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
+                }
             }
         }
     }
@@ -565,7 +590,6 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
             float2 x;
             if constexpr (NF == 2) x = load.post(id, l, v[it], v2[it]);
             else x = load.post(id, l, v[it]);
-            if (partial && wl >= wvalid) x = make_float2(0.f, 0.f);
             if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
         }
         __syncthreads();
@@ -580,10 +604,11 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
                 float2* x = &v[it * R0];
 #pragma unroll
                 for (int q = 0; q < R0; ++q) {
-                    if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
+                    if constexpr (HZ) {
+                        if (zone(q) != 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q], zone(q));
+                    } else if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
                     else if constexpr (CTX) x[q] = load.post(id, b + q * m0, x[q], ctx);
                     else x[q] = load.post(id, b + q * m0, x[q]);
-                    if (partial && w >= wvalid) x[q] = make_float2(0.f, 0.f);
                 }
                 dft_p<R0>(x);
 #pragma unroll
@@ -674,7 +699,6 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
     const int i0 = blockIdx.x * W;
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
-    const bool partial = wvalid < W;   // workgroup-uniform: only the last tile of a row masks lanes
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
     const int64_t mid_base = (int64_t)id.batch * d1.out_batch + i0;      // natural-order signal
     const int64_t out_base = (int64_t)id.batch * d2.out_batch + i0;
@@ -730,7 +754,6 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
         const int wl = e / L, l = e - wl * L;
         id.i = i0 + wl;
         float2 x = load.post(id, l, v[it]);
-        if (wl >= wvalid) x = make_float2(0.f, 0.f);
         if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
     }
     __syncthreads();
@@ -768,7 +791,6 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
             for (int q = 0; q < RL; ++q) {
                 const int k = kb + (L / RL) * q;
                 float2 y = mid(id, k, xr[it * RL + dft_slot<RL>(q)], aux[it * RL + q]);
-                if (partial && w >= wvalid) y = make_float2(0.f, 0.f);
                 tile[lds_slot<true>(k, w)] = y;
             }
         }

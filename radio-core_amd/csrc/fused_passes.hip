@@ -148,35 +148,50 @@ struct LoadRealPair {
 
 // Hilbert mask applied to one member of such a pair: with U = FFT(x0 + j x1),
 // X0[k] = (U[k] + conj U[-k]) / 2, X1[k] = (U[k] - conj U[-k]) / 2j; Z = h X, bins above n/2 are 0.
-struct LoadHilbertPair {
+// HZ: the pass is the first of a two-pass plan of even length (point k = l * stride + i, n = L *
+// stride), so the kernel may skip everything above the middle (fft_kernel.h, kHalfZones).
+template <bool HZ>
+struct LoadHilbertPairT {
     static constexpr int kFetches = 2;
+    static constexpr bool kHalfZones = HZ;
     const float2* U;     // [ceil(count / 2)][n]
     int n;
-    int64_t line_stride;
-    __device__ __forceinline__ int bin(const LineId&, int64_t base, unsigned off) const {
-        return (int)(base + off);   // in_batch = 0
+    int line_stride;
+    __device__ __forceinline__ const float2* pair(const LineId& id) const {
+        return U + (int64_t)(id.batch >> 1) * n;
     }
-    __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
-        const int k = bin(id, base, off);
-        return U[(int64_t)(id.batch >> 1) * n + (k <= n / 2 ? k : 0)];
+    // zone 0: 0 <= k < n/2 is known; zone 1: anything
+    __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t, unsigned, int zone = 1) const {
+        const int k = l * line_stride + (int)id.i;
+        return pair(id)[(zone == 0 || k <= n / 2) ? k : 0];
     }
-    __device__ __forceinline__ float2 fetch2(const LineId& id, int, int64_t base, unsigned off) const {
-        const int k = bin(id, base, off);
-        return U[(int64_t)(id.batch >> 1) * n + ((k <= n / 2 && k > 0) ? n - k : 0)];
+    __device__ __forceinline__ float2 fetch2(const LineId& id, int l, int64_t, unsigned, int zone = 1) const {
+        const int k = l * line_stride + (int)id.i;
+        return pair(id)[((zone == 0 || k <= n / 2) && k > 0) ? n - k : 0];
     }
-    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 a, float2 b) const {
-        const int k = (int)(l * line_stride + id.i);
-        float h = 0.f;
-        if (k == 0) h = 1.f;
-        else if (k < (n + 1) / 2) h = 2.f;
-        else if ((n & 1) == 0 && k == n / 2) h = 1.f;
-        h *= 0.5f;
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 a, float2 b, int zone = 1) const {
+        const int k = l * line_stride + (int)id.i;
+        float h = (k == 0) ? 0.5f : 1.f;   // h / 2 of scipy.signal.hilbert's {1, 2, ..., 2, (1), 0, ...}
+        if (zone != 0) {
+            if (k >= (n + 1) / 2) h = 0.f;
+            if ((n & 1) == 0 && k == n / 2) h = 0.5f;
+        }
         float2 xk;
         if ((id.batch & 1) == 0) xk = make_float2(a.x + b.x, a.y - b.y);          // U[k] + conj U[-k]
         else xk = make_float2(a.y + b.y, -(a.x - b.x));                           // (U[k] - conj U[-k]) / j
         return make_float2(xk.y * h, xk.x * h);   // swapped: inverse transform
     }
 };
+
+template <class Launch>
+void with_hilbert_pair_load(const FftEngine& e, const float2* U, Launch&& launch) {
+    const FftPass& p = e.desc().pass[0];
+    const int64_t n = e.desc().n;
+    if (e.npass() == 2 && !p.load_along_l && p.in_l * p.L == n && p.L % 2 == 0)
+        launch(LoadHilbertPairT<true>{U, (int)n, (int)p.in_l});
+    else
+        launch(LoadHilbertPairT<false>{U, (int)n, (int)p.in_l});
+}
 
 // scipy.signal.hilbert's mask on the full spectrum U: h = {1, 2, ..., 2, (1), 0, ...}.
 struct LoadHilbertMask {
@@ -199,6 +214,16 @@ struct LoadHilbertMask {
     }
 };
 
+// wbfm.py:83,86-87 for one sample: z = (v.y, v.x) (swap identity), s2 = Im(z^2)/|z^2| = 2ab / (a^2 + b^2),
+// lmr = s2 m 1.0175, packed (m + lmr, m - lmr).  One v_rcp_f32 (1 ulp); like pll.py:57-58 in complex64
+// the quotient is NaN for z == 0 and meaningless once |z|^2 leaves the float32 range.
+__device__ __forceinline__ float2 stereo_mix_point(float2 v, float mm) {
+    const float q = fmaf(v.x, v.x, v.y * v.y);
+    const float s2 = (2.f * v.x * v.y) * __builtin_amdgcn_rcpf(q);
+    const float lmr = (s2 * mm) * 1.0175f;
+    return make_float2(mm + lmr, mm - lmr);
+}
+
 // Last pass of the analytic-signal IFFT: z (still swapped) -> stereo mix -> packed u.
 struct StoreStereoMix {
     static constexpr bool kAux = true;   // m[n] is fetched with the tile's loads
@@ -209,13 +234,7 @@ struct StoreStereoMix {
     }
     __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v,
                                                float mm) const {
-        // z = (v.y, v.x); Im(z^2)/|z^2| = 2 ab / (a^2 + b^2), pre-scaled against underflow;
-        // z == 0 gives NaN like pll.py:57-58
-        const float inv = __frcp_rn(fmaxf(fabsf(v.x), fabsf(v.y)));
-        const float za = v.y * inv, zb = v.x * inv;
-        const float s2 = (2.f * za * zb) * __frcp_rn(za * za + zb * zb);
-        const float lmr = (s2 * mm) * 1.0175f;
-        fftk::stream_store(u + base + off, make_float2(mm + lmr, mm - lmr));
+        fftk::stream_store(u + base + off, stereo_mix_point(v, mm));
     }
 };
 
@@ -227,11 +246,7 @@ struct MidStereoMix {
         return (m + base)[off];
     }
     __device__ __forceinline__ float2 operator()(const LineId&, int, float2 v, float mm) const {
-        const float inv = __frcp_rn(fmaxf(fabsf(v.x), fabsf(v.y)));
-        const float za = v.y * inv, zb = v.x * inv;           // z = (v.y, v.x): swap identity
-        const float s2 = (2.f * za * zb) * __frcp_rn(za * za + zb * zb);
-        const float lmr = (s2 * mm) * 1.0175f;
-        return make_float2(mm + lmr, mm - lmr);
+        return stereo_mix_point(v, mm);
     }
 };
 
@@ -366,9 +381,10 @@ void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U, const floa
     if (count <= 0) return;
     const int64_t n = e.desc().n;
     const int np = e.npass();
-    LoadHilbertPair ld{U, (int)n, e.desc().pass[0].in_l};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), count, ld, st0, s);
+    with_hilbert_pair_load(e, U, [&](auto ld) {
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), count, ld, st0, s);
+    });
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     StoreStereoMix stl{m, u};
@@ -383,9 +399,10 @@ bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, c
     const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);
     const FftPassDev d2 = ef.pass_dev(0, n, ef.tmp_stride());
     if (!fftk::fft_tile2_applies(d1, d2, count)) return false;   // decided before anything is launched
-    LoadHilbertPair ld{U, (int)n, ei.desc().pass[0].in_l};
     fftk::StorePlainT<false> st0{tmp_i, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(ei.pass_dev(0, 0, ei.tmp_stride()), count, ld, st0, s);
+    with_hilbert_pair_load(ei, U, [&](auto ld) {
+        fftk::launch_fft_pass<kStridedOnly>(ei.pass_dev(0, 0, ei.tmp_stride()), count, ld, st0, s);
+    });
     fftk::LoadPlainT<false> ldl{tmp_i};
     MidStereoMix mid{m};
     fftk::StorePlainT<false> st1{tmp_f, 1.0f};
