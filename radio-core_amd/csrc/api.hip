@@ -447,7 +447,10 @@ struct rcfm_demod_s {
                     // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
                     // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
                     StageTimer tm(ST_IFFT_B, s);
-                    paired = fused_hilbert_pair_ifft_mix_fft(*eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s);
+                    static const bool unpacked = std::getenv("RCFM_HILBERT_UNPACK") != nullptr;   // A/B
+                    paired = unpacked ? fused_hilbert_pair_ifft_mix_fft(*eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s)
+                                      : fused_hilbert_packed_ifft_mix_fft(*eng_Bi, *eng_B, U2, p, m,
+                                                                          buf_Ti.as<float2>(), T, cnt, s);
                 }
                 if (paired) {
                     StageTimer tm(ST_FFT_B, s);

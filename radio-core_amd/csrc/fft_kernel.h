@@ -364,6 +364,22 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
 // butterfly; the 16 lanes of a row always touch one 128-byte LDS row / global segment.
 // Grid: x = tile along the inner line index, y = outer line index, z = signal in the batch.
 
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by linear id (x fastest), and
+// each XCD has its own L2.  Neighbouring tiles of a row share 128-byte lines whenever a functor reads
+// 64-byte or unaligned segments (real inputs, the tuner's rolled spectrum); mapping x -> tile so that
+// each XCD owns a contiguous eighth of the row lets the second reader hit the first one's L2 line.
+#ifndef RCFM_FFT_XCD_ORDER
+#define RCFM_FFT_XCD_ORDER 1
+#endif
+__device__ __forceinline__ unsigned tile_of_block() {
+#if RCFM_FFT_XCD_ORDER
+    const unsigned gx = gridDim.x, x = blockIdx.x;
+    return (gx & 7u) ? x : (x & 7u) * (gx >> 3) + (x >> 3);
+#else
+    return blockIdx.x;
+#endif
+}
+
 // Small DFTs that leave output q' in slot perm<R>(q') (no register shuffling afterwards).
 template <int R>
 __device__ __forceinline__ constexpr int dft_slot(int q) {
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     const unsigned o = blockIdx.y, n_o2 = (unsigned)p.n_o2;
     id.o1 = n_o2 == 1 ? o : o / n_o2;
     id.o2 = n_o2 == 1 ? 0 : o - (unsigned)id.o1 * n_o2;
-    const int i0 = blockIdx.x * W;
+    const int i0 = (int)tile_of_block() * W;
     const int left = (int)p.n_inner - i0;
     // Lanes past the end of a row (last tile only) load line 0 of the tile again and are never stored:
     // every lane transforms its own line, so nothing has to be masked in between.
@@ -519,14 +535,14 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
             for (int q = 0; q < R0; ++q) {
                 const int l = b + q * m0;
                 if constexpr (HZ) {
-                    static_assert(NF == 2, "half zones: two-fetch load functors");
                     const int z = zone(q);
                     if (z == 2) {
                         v[it * R0 + q] = make_float2(0.f, 0.f);
-                        v2[it * R0 + q] = make_float2(0.f, 0.f);
+                        if constexpr (NF == 2) v2[it * R0 + q] = make_float2(0.f, 0.f);
                     } else {
                         v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc, z);
-                        v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc, z);
+                        if constexpr (NF == 2)
+                            v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc, z);
                     }
                 } else {
                     v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
@@ -605,7 +621,11 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
 #pragma unroll
                 for (int q = 0; q < R0; ++q) {
                     if constexpr (HZ) {
-                        if (zone(q) != 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q], zone(q));
+                        if constexpr (NF == 2) {
+                            if (zone(q) != 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q], zone(q));
+                        } else {
+                            if (zone(q) != 2) x[q] = load.post(id, b + q * m0, x[q], zone(q));
+                        }
                     } else if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
                     else if constexpr (CTX) x[q] = load.post(id, b + q * m0, x[q], ctx);
                     else x[q] = load.post(id, b + q * m0, x[q]);
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
     id.batch = blockIdx.z;
     id.o1 = 0;
     id.o2 = 0;
-    const int i0 = blockIdx.x * W;
+    const int i0 = (int)tile_of_block() * W;
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
@@ -832,6 +852,212 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
             }
         }
     }
+}
+
+// ---- one inverse transform in, two forward transforms out ------------------------------
+//
+// k_fft_tile2 for PAIRS of real signals that travelled through one complex transform: the first
+// transform's line belongs to pair P = blockIdx.z; the point-wise stage turns each of its values w
+// into one value per member (channels 2P and 2P+1), and each member gets its own second transform
+// (same tile, one after the other; the second member waits in registers).  Used by WBFM: the
+// analytic signals of two pilots come out of ONE masked inverse FFT (fused_passes.h).
+//
+// MidOp contract (natural-order point `off` of the tile, channel bases b0 / b1 in signal samples):
+//   In0 fetch0(b0, b1, off)          inputs needed for member 0 and for the split (issued early)
+//   float fetch1(b1, off)            what member 1 still needs (issued while member 0 transforms)
+//   float2 first(w, In0, Keep&)      member 0's value; Keep = what member 1 needs later
+//   float2 second(Keep, float)       member 1's value
+template <int L, int R0, int R1, int R2, int R3, int T, class LoadOp, class MidOp, class StoreOp>
+__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPassDev d1, FftPassDev d2, LoadOp load,
+                                                                          MidOp mid, StoreOp store, int count) {
+    constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
+    constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;
+    constexpr int RG = T / W;
+    constexpr int nld = (L * W + T - 1) / T;
+    constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
+    __shared__ __attribute__((aligned(16))) float2 tile[L * kRowsPitch];
+    __shared__ __attribute__((aligned(16))) float2 tw[L];
+    const FftPass& p1 = d1.p;
+    const FftPass& p2 = d2.p;
+    const int tid = threadIdx.x;
+    const int w = tid & (W - 1), rg = tid >> 4;
+
+    LineId id;
+    id.batch = blockIdx.z;   // pair index
+    id.o1 = 0;
+    id.o2 = 0;
+    const int c0 = 2 * (int)blockIdx.z;
+    const bool has1 = c0 + 1 < count;          // an odd count leaves the last pair with one member
+    const int c1 = has1 ? c0 + 1 : c0;
+    const int i0 = (int)tile_of_block() * W;
+    const int left = (int)p1.n_inner - i0;
+    const int wvalid = left < W ? left : W;
+    const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
+    const int64_t mid_base0 = (int64_t)c0 * d1.out_batch + i0;      // natural-order signals of the members
+    const int64_t mid_base1 = (int64_t)c1 * d1.out_batch + i0;
+    const int64_t out_base0 = (int64_t)c0 * d2.out_batch + i0;
+    const int64_t out_base1 = (int64_t)c1 * d2.out_batch + i0;
+    const unsigned in_i = (unsigned)p1.in_i, mid_k = (unsigned)p1.out_k, out_k = (unsigned)p2.out_k;
+    const int wc = w < wvalid ? w : 0;
+
+    auto kbase = [](int g) -> int {
+        if constexpr (S == 2) {
+            return g;
+        } else if constexpr (S == 3) {
+            constexpr int w1 = L / (R0 * RL);
+            const int q1 = g / w1, q2 = g - q1 * w1;
+            return q1 + R0 * q2;
+        } else {
+            constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
+            const int q1 = g / w1, r1 = g - q1 * w1;
+            const int q2 = r1 / w2, q3 = r1 - q2 * w2;
+            return q1 + R0 * (q2 + R1 * q3);
+        }
+    };
+    // Natural-order offset of point (it, q) of this thread = lane part (it) + uniform part (q): the
+    // uniform part goes into the scalar base, so a thread holds nitL offsets instead of nitL * RL.
+    auto lane_off = [&](int it) -> unsigned {
+        int g = rg + RG * it;
+        if (rowsL % RG != 0) g = g < rowsL ? g : 0;
+        return (unsigned)kbase(g) * mid_k + (unsigned)wc;
+    };
+    auto q_off = [&](int q) -> int64_t { return (int64_t)((L / RL) * q) * mid_k; };
+
+    // ---- loads of the first transform (contiguous lines) ------------------------------------
+    float2 v[nld];
+#pragma unroll
+    for (int it = 0; it < nld; ++it) {
+        int e = tid + T * it;
+        if ((L * W) % T != 0) e = e < L * W ? e : 0;
+        const int wl = e / L, l = e - wl * L;
+        const int wcl = wl < wvalid ? wl : 0;
+        id.i = i0 + wcl;
+        v[it] = load.fetch(id, l, in_base, (unsigned)wcl * in_i + (unsigned)l);
+    }
+    for (int e = tid; e < L; e += T) tw[e] = d1.stage_tw[e];
+#pragma unroll
+    for (int it = 0; it < nld; ++it) {
+        const int e = tid + T * it;
+        const int wl = e / L, l = e - wl * L;
+        id.i = i0 + wl;
+        const float2 x = load.post(id, l, v[it]);
+        if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
+    }
+    __syncthreads();
+    stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+    __syncthreads();
+    if constexpr (S >= 3) {
+        stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+    if constexpr (S >= 4) {
+        stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+
+    // ---- point-wise inputs of member 0 (and of the split), then the last stage ----------------
+    using In0 = decltype(mid.fetch0(mid_base0, mid_base1, 0u));
+    In0 a0[nitL * RL];
+#pragma unroll
+    for (int it = 0; it < nitL; ++it)
+#pragma unroll
+        for (int q = 0; q < RL; ++q)
+            a0[it * RL + q] = mid.fetch0(mid_base0 + q_off(q), mid_base1 + q_off(q), lane_off(it));
+
+    // Last stage of the first transform and the split, one butterfly row at a time (the inputs a0
+    // retire as the values u0 / keep appear: fewer registers than holding all of w first).
+    id.i = i0 + w;
+    using Keep = typename MidOp::Keep;
+    float2 u0[nitL * RL];
+    Keep keep[nitL * RL];
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            float2 x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
+            dft_p<RL>(x);
+#pragma unroll
+            for (int q = 0; q < RL; ++q)
+                u0[it * RL + q] = mid.first(x[dft_slot<RL>(q)], a0[it * RL + q], keep[it * RL + q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisted LDS reads of the next rows would spill
+    }
+    __syncthreads();   // every slot has been read
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) tile[lds_slot<true>(kb + (L / RL) * q, w)] = u0[it * RL + q];
+        }
+    }
+    __syncthreads();
+
+    // ---- second transform (a strided pass of plan 2 whose input already sits in LDS), per member
+    const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
+    const float2 D = big_twiddle(d2, f * (unsigned)(L / RL));
+    const bool lane_ok = w < wvalid;
+    auto second_transform = [&](int64_t out_base) {
+        stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+        __syncthreads();
+        if constexpr (S >= 3) {
+            stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
+            __syncthreads();
+        }
+        if constexpr (S >= 4) {
+            stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < nitL; ++it) {
+            const int g = rg + RG * it;
+            if ((rowsL % RG == 0) || g < rowsL) {
+                float2 x[RL];
+#pragma unroll
+                for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
+                dft_p<RL>(x);
+                const int kb = kbase(g);
+                float2 Tw = big_twiddle(d2, f * (unsigned)kb);
+                if (lane_ok) {
+#pragma unroll
+                    for (int q = 0; q < RL; ++q) {
+                        const int k = kb + (L / RL) * q;
+                        const float2 y = cmul(x[dft_slot<RL>(q)], Tw);
+                        Tw = cmul(Tw, D);
+                        store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
+                    }
+                }
+            }
+        }
+    };
+
+    float a1[nitL * RL];
+#pragma unroll
+    for (int it = 0; it < nitL; ++it)
+#pragma unroll
+        for (int q = 0; q < RL; ++q) a1[it * RL + q] = mid.fetch1(mid_base1 + q_off(q), lane_off(it));
+
+    second_transform(out_base0);
+    if (!has1) return;   // workgroup-uniform
+    __syncthreads();     // member 0's last stage has read every slot
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const int k = kb + (L / RL) * q;
+                tile[lds_slot<true>(k, w)] = mid.second(keep[it * RL + q], a1[it * RL + q]);
+            }
+        }
+    }
+    __syncthreads();
+    second_transform(out_base1);
 }
 
 // ---- plain functors ------------------------------------------------------------
@@ -971,6 +1197,27 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
     return fast && !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L &&
            d1.p.n_inner == d2.p.n_inner && d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 &&
            d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
+}
+
+// The pair form: `count` member signals, ceil(count / 2) first transforms.
+template <class LoadOp, class MidOp, class StoreOp>
+inline bool launch_fft_tile2_pair(const FftPassDev& d1, const FftPassDev& d2, int count, const LoadOp& ld,
+                                  const MidOp& mid, const StoreOp& st, hipStream_t s) {
+    const int pairs = (count + 1) / 2;
+    if (!fft_tile2_applies(d1, d2, pairs)) return false;
+    const dim3 grid((unsigned)((d1.p.n_inner + W - 1) / W), 1, (unsigned)pairs);
+    switch (d1.p.L) {
+#define RCFM_CASE(LEN, A, B, C, D)                                                                               \
+    case LEN:                                                                                                    \
+        hipLaunchKernelGGL((k_fft_tile2_pair<LEN, A, B, C, D, tile_threads(LEN), LoadOp, MidOp, StoreOp>), grid, \
+                           dim3(tile_threads(LEN)), 0, s, d1, d2, ld, mid, st, count);                           \
+        break;
+        RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+#undef RCFM_CASE
+        default: return false;
+    }
+    RC_HIP(hipGetLastError());
+    return true;
 }
 
 template <class LoadOp, class MidOp, class StoreOp>

@@ -51,6 +51,11 @@ void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const flo
 // Returns false (nothing launched) when the two plans do not pair up.
 bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* m,
                                      float2* tmp_i, float2* tmp_f, int count, hipStream_t s);
+// The same chain with the PAIR kept packed through the inverse transform: w = IFFT(h U2) = z0 + j z1
+// (z_c = p_c + j Hilbert(p_c)), so Hilbert(p1) = p0 - Re w and Hilbert(p0) = Im w - p1: one inverse
+// transform per two channels; the mix reads p as well as m (k_fft_tile2_pair).
+bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* p,
+                                       const float* m, float2* tmp_i, float2* tmp_f, int count, hipStream_t s);
 void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,
                            hipStream_t s);
 

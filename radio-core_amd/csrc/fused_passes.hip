@@ -183,6 +183,30 @@ struct LoadHilbertPairT {
     }
 };
 
+// scipy.signal.hilbert's mask h = {1, 2, ..., 2, (1), 0, ...} times `scale` on a packed spectrum
+// U2 [pairs][n] (no unpacking: the pair stays packed through the inverse transform).
+template <bool HZ>
+struct LoadHilbertPackedT {
+    static constexpr bool kHalfZones = HZ;
+    const float2* U2;
+    int n;
+    int line_stride;
+    float scale;
+    __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t, unsigned, int zone = 1) const {
+        const int k = l * line_stride + (int)id.i;
+        return (U2 + (int64_t)id.batch * n)[(zone == 0 || k <= n / 2) ? k : 0];
+    }
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 v, int zone = 1) const {
+        const int k = l * line_stride + (int)id.i;
+        float h = (k == 0) ? scale : 2.f * scale;
+        if (zone != 0) {
+            if (k >= (n + 1) / 2) h = 0.f;
+            if ((n & 1) == 0 && k == n / 2) h = scale;
+        }
+        return make_float2(v.y * h, v.x * h);   // swapped: inverse transform
+    }
+};
+
 template <class Launch>
 void with_hilbert_pair_load(const FftEngine& e, const float2* U, Launch&& launch) {
     const FftPass& p = e.desc().pass[0];
@@ -217,9 +241,11 @@ struct LoadHilbertMask {
 // wbfm.py:83,86-87 for one sample: z = (v.y, v.x) (swap identity), s2 = Im(z^2)/|z^2| = 2ab / (a^2 + b^2),
 // lmr = s2 m 1.0175, packed (m + lmr, m - lmr).  One v_rcp_f32 (1 ulp); like pll.py:57-58 in complex64
 // the quotient is NaN for z == 0 and meaningless once |z|^2 leaves the float32 range.
+__device__ __forceinline__ float pilot_carrier(float a, float b) {   // Im(z^2)/|z^2|, z = a + j b
+    return (2.f * a * b) * __builtin_amdgcn_rcpf(fmaf(a, a, b * b));
+}
 __device__ __forceinline__ float2 stereo_mix_point(float2 v, float mm) {
-    const float q = fmaf(v.x, v.x, v.y * v.y);
-    const float s2 = (2.f * v.x * v.y) * __builtin_amdgcn_rcpf(q);
+    const float s2 = pilot_carrier(v.y, v.x);
     const float lmr = (s2 * mm) * 1.0175f;
     return make_float2(mm + lmr, mm - lmr);
 }
@@ -247,6 +273,35 @@ struct MidStereoMix {
     }
     __device__ __forceinline__ float2 operator()(const LineId&, int, float2 v, float mm) const {
         return stereo_mix_point(v, mm);
+    }
+};
+
+// The same mix for PAIRS of channels whose pilots went through one complex transform
+// (k_fft_tile2_pair): U2 = FFT(p0 + j p1), w = IFFT(h U2) = z0 + j z1 with z_c = p_c + j H_c, so
+// H1 = p0 - Re w and H0 = Im w - p1: one masked inverse FFT yields both analytic signals.
+struct MidStereoMixPair {
+    const float* p;   // [count][n] pilot bands
+    const float* m;   // [count][n] mono signals
+    struct In0 { float p0, p1, m0; };
+    using Keep = float;   // member 1's carrier s2 = Im(z1^2)/|z1^2|
+    // uniform 64-bit base + 32-bit lane byte offset: one VGPR of address per point, shared by the
+    // three streams (54 loads per thread are in flight together)
+    static __device__ __forceinline__ float at(const float* base, unsigned off) {
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(off * 4u));
+    }
+    __device__ __forceinline__ In0 fetch0(int64_t b0, int64_t b1, unsigned off) const {
+        return In0{at(p + b0, off), at(p + b1, off), at(m + b0, off)};
+    }
+    __device__ __forceinline__ float fetch1(int64_t b1, unsigned off) const { return at(m + b1, off); }
+    // v = w with re/im exchanged (inverse transform by the swap identity)
+    __device__ __forceinline__ float2 first(float2 v, const In0& a, Keep& s2_1) const {
+        s2_1 = pilot_carrier(a.p1, a.p0 - v.y);
+        const float lmr = (pilot_carrier(a.p0, v.x - a.p1) * a.m0) * 1.0175f;
+        return make_float2(a.m0 + lmr, a.m0 - lmr);
+    }
+    __device__ __forceinline__ float2 second(const Keep& s2_1, float m1) const {
+        const float lmr = (s2_1 * m1) * 1.0175f;
+        return make_float2(m1 + lmr, m1 - lmr);
     }
 };
 
@@ -408,6 +463,32 @@ bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, c
     fftk::StorePlainT<false> st1{tmp_f, 1.0f};
     RC_REQUIRE(fftk::launch_fft_tile2(d1, d2, count, ldl, mid, st1, s), RCFM_ERR_RUNTIME,
                "two-transform tile kernel refused a pair it should accept");
+    return true;
+}
+
+bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* p,
+                                       const float* m, float2* tmp_i, float2* tmp_f, int count, hipStream_t s) {
+    if (count <= 0) return true;
+    if (ei.npass() != 2 || ef.npass() != 2 || ei.desc().n != ef.desc().n) return false;
+    const int64_t n = ei.desc().n;
+    const int pairs = (count + 1) / 2;
+    const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);
+    const FftPassDev d2 = ef.pass_dev(0, n, ef.tmp_stride());
+    if (!fftk::fft_tile2_applies(d1, d2, pairs)) return false;   // decided before anything is launched
+    fftk::StorePlainT<false> st0{tmp_i, 1.0f};
+    const FftPass& p0 = ei.desc().pass[0];
+    const float scale = (float)(1.0 / (double)n);
+    if (!p0.load_along_l && p0.in_l * p0.L == n && p0.L % 2 == 0)
+        fftk::launch_fft_pass<kStridedOnly>(ei.pass_dev(0, 0, ei.tmp_stride()), pairs,
+                                            LoadHilbertPackedT<true>{U2, (int)n, (int)p0.in_l, scale}, st0, s);
+    else
+        fftk::launch_fft_pass<kStridedOnly>(ei.pass_dev(0, 0, ei.tmp_stride()), pairs,
+                                            LoadHilbertPackedT<false>{U2, (int)n, (int)p0.in_l, scale}, st0, s);
+    fftk::LoadPlainT<false> ldl{tmp_i};
+    MidStereoMixPair mid{p, m};
+    fftk::StorePlainT<false> st1{tmp_f, 1.0f};
+    RC_REQUIRE(fftk::launch_fft_tile2_pair(d1, d2, count, ldl, mid, st1, s), RCFM_ERR_RUNTIME,
+               "two-transform pair kernel refused a pair it should accept");
     return true;
 }
 
