@@ -259,102 +259,199 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage(const float2* __restri
 // Each thread produces 8 consecutive outputs from an 88-sample window held in registers
 // (22 ds_read_b128 instead of 648 ds_read_b32); the 41 distinct taps arrive as kernel
 // arguments (SGPRs).  Blocks that touch either end of the buffer take the reflecting path.
+// The 81-tap zero-phase kernel h[t] = g[|t - 40|] as 41 pairs (h[2j], h[2j+1]), h[81] = 0 (kernel
+// arguments: they reach the FIR as SGPR pairs).
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct PilotTaps {
-    float g[41];
+    v2f pair[41];
 };
 
 constexpr int kPilotPer = 8;
 constexpr int kPilotFastTile = kThreads * kPilotPer;   // 2048 outputs per workgroup
 
+// acc += taps (.) w and acc += reverse(taps) (.) w, taps in an SGPR pair: the halves are picked by
+// op_sel, so the symmetric kernel serves even and odd outputs from one set of aligned pairs.
+__device__ __forceinline__ void pk_fma_s(v2f& acc, v2f taps, v2f w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(taps), "v"(w));
+}
+__device__ __forceinline__ void pk_fma_s_rev(v2f& acc, v2f taps, v2f w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(taps), "v"(w));
+}
+
+// atan2(y, x) / pi for the discriminator: odd minimax polynomial of min/max (degree 17, 1e-7 rad),
+// octant folding by selects; (0, 0) -> 0 like numpy.angle.
+__device__ __forceinline__ float atan2_over_pi(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float t = a * a;
+    float p = 0.002479950897395611f;
+    p = fmaf(p, t, -0.014499950222671032f);
+    p = fmaf(p, t, 0.039953526109457016f);
+    p = fmaf(p, t, -0.0725083202123642f);
+    p = fmaf(p, t, 0.10507379472255707f);
+    p = fmaf(p, t, -0.14163753390312195f);
+    p = fmaf(p, t, 0.19986307621002197f);
+    p = fmaf(p, t, -0.3333262503147125f);
+    p = fmaf(p, t, 0.9999998807907104f);
+    float r = (p * a) * kInvPi;          // [0, 1/4]
+    r = (ay > ax) ? 0.5f - r : r;        // [0, 1/2]
+    r = (x < 0.f) ? 1.f - r : r;         // [0, 1]
+    return copysignf(r, y);
+}
+__device__ __forceinline__ float phase_step_fast(float2 a, float2 b) {
+    return atan2_over_pi(a.y * b.x - a.x * b.y, a.x * b.x + a.y * b.y);
+}
+
 __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const float2* __restrict__ iq,
                                                               float* __restrict__ m_out,
                                                               float* __restrict__ p_out, int64_t n,
-                                                              PilotTaps taps, float side_tap) {
+                                                              PilotTaps taps, float side_tap,
+                                                              unsigned tiles_x, unsigned batch) {
     constexpr int H = 40, T = kPilotFastTile, PER = kPilotPer;
     __shared__ __attribute__((aligned(16))) float m_s[T + 2 * H];        // m[q0 + s]
     __shared__ __attribute__((aligned(16))) float d_s[T + 2 * H + 2];    // d[q0 - 1 + s] (circular)
-    const int c = blockIdx.y;
+    // XCD-aware order (workgroups go to the 8 XCDs round-robin, each XCD has its own L2): XCD k walks
+    // a contiguous eighth of the (channel, tile) list, so the halo lines two neighbouring tiles share
+    // are fetched once.  1-D grid of 8 * ceil(tiles * batch / 8) workgroups.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned vid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= tiles_x * batch) return;
+    const int c = (int)(vid / tiles_x);
     const int tid = threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.x * T;
-    const int64_t q0 = t0 - H;
+    const int n32 = (int)n;
+    const int t0 = (int)(vid - (unsigned)c * tiles_x) * T;
+    const int q0 = t0 - H;
     const float2* xc = iq + (int64_t)c * n;
+    // workgroup-uniform: the tile and its halos lie strictly inside the channel (no wrap, no reflection)
+    const bool interior = (q0 - 2 >= 0) && (q0 + T + 2 * H + 1 <= n32 - 1);
     // discriminator: both samples of every pair are fetched unconditionally (clamped index) and
     // up front, 18 loads in flight per thread; a load inside the loop's `if` would serialise
     // one HBM round trip per iteration
     constexpr int ND = (T + 2 * H + 2 + kThreads - 1) / kThreads;
     float2 xa[ND], xb[ND];
+    if (interior) {
+        const float2* x0 = xc + (q0 - 1 + tid);
 #pragma unroll
-    for (int it = 0; it < ND; ++it) {
-        int64_t i = q0 - 1 + tid + kThreads * it;
-        if (i == -1) i = n - 1;   // the same-size Decimate is circular (decimate.py:48)
-        if (i == n) i = 0;
-        i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
-        xa[it] = xc[i];
-        xb[it] = xc[i - 1];
-    }
-#pragma unroll
-    for (int it = 0; it < ND; ++it) {
-        const int s = tid + kThreads * it;
-        const int64_t i = q0 - 1 + s;
-        // d[0] = 0 (fm.py:64); i == n wraps to d[0]; outside [-1, n] is never read
-        const bool live = (i == -1) || (i > 0 && i < n);
-        const float v = live ? phase_step(xa[it], xb[it]) : 0.f;
-        if (s < T + 2 * H + 2) d_s[s] = v;
-    }
-    __syncthreads();
-    for (int s = tid; s < T + 2 * H; s += kThreads) {
-        const int64_t q = q0 + s;
-        float v = 0.f;
-        if (q >= 0 && q < n) {
-            v = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
-            if (q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
+        for (int it = 0; it < ND; ++it) {
+            // the last sweep is ragged: clamp instead of branching (the value is not stored)
+            const int off = (it == ND - 1 && tid + kThreads * it >= T + 2 * H + 2) ? 0 : kThreads * it;
+            xa[it] = x0[off];
+            xb[it] = x0[off - 1];
         }
-        m_s[s] = v;
+#pragma unroll
+        for (int it = 0; it < ND; ++it) {
+            const int s = tid + kThreads * it;
+            const float v = phase_step_fast(xa[it], xb[it]);
+            if (it < ND - 1 || s < T + 2 * H + 2) d_s[s] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (T + 2 * H + kThreads - 1) / kThreads; ++it) {
+            const int s = tid + kThreads * it;
+            if (s < T + 2 * H) {
+                m_s[s] = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ND; ++it) {
+            int i = q0 - 1 + tid + kThreads * it;
+            if (i == -1) i = n32 - 1;   // the same-size Decimate is circular (decimate.py:48)
+            if (i == n32) i = 0;
+            i = i < 1 ? 1 : (i > n32 - 1 ? n32 - 1 : i);
+            xa[it] = xc[i];
+            xb[it] = xc[i - 1];
+        }
+#pragma unroll
+        for (int it = 0; it < ND; ++it) {
+            const int s = tid + kThreads * it;
+            const int i = q0 - 1 + s;
+            // d[0] = 0 (fm.py:64); i == n wraps to d[0]; outside [-1, n] is never read
+            const bool live = (i == -1) || (i > 0 && i < n32);
+            const float v = live ? phase_step_fast(xa[it], xb[it]) : 0.f;
+            if (s < T + 2 * H + 2) d_s[s] = v;
+        }
+        __syncthreads();
+        for (int s = tid; s < T + 2 * H; s += kThreads) {
+            const int q = q0 + s;
+            float v = 0.f;
+            if (q >= 0 && q < n32) {
+                v = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
+                if (q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
+            }
+            m_s[s] = v;
+        }
     }
     __syncthreads();
 
-    const int64_t last = n - 1;
+    const int last = n32 - 1;
     const int o = tid * PER;
+    if (interior) {   // m leaves as 16-byte stores like p
+        float4* dst = reinterpret_cast<float4*>(m_out + (int64_t)c * n + t0 + o);
+        dst[0] = *reinterpret_cast<const float4*>(&m_s[H + o]);
+        dst[1] = *reinterpret_cast<const float4*>(&m_s[H + o + 4]);
+    }
     if (t0 - H >= 0 && t0 + T - 1 + H <= last) {   // workgroup-uniform: no reflection anywhere in the tile
-        float w[PER + 2 * H];
+        // out[r] = sum_t h[t] w[r + t], t = 0..80, w = m_s + o, two taps per packed FMA (lane 0: the
+        // even t of the pair, lane 1: the odd one).  Even r: pairs (t, t+1) = (2j, 2j+1) sit on aligned
+        // window pairs j + r/2.  Odd r: t = 0 alone, then pairs (t, t+1), t = 79 - 2j odd, whose taps
+        // are pair j reversed (h is symmetric) and whose window pair is 40 - j + (r-1)/2.  No operand
+        // shuffling: 41 instructions per output.  The two 4-pair windows slide in opposite directions
+        // and are read from LDS as they are needed (16 live registers instead of the 88 of the whole
+        // window: twice the waves per SIMD, which is what hides the HBM latency of the next tile).
+        auto wpair = [&](int pi) -> v2f {
+            v2f q = *reinterpret_cast<const v2f*>(&m_s[o + 2 * pi]);
+            asm volatile("" : "+v"(q));   // keep the 8-byte read (and its place in the sequence)
+            return q;
+        };
+        v2f acc[PER];
 #pragma unroll
-        for (int j = 0; j < (PER + 2 * H) / 4; ++j) {
-            float4 q4 = *reinterpret_cast<const float4*>(&m_s[o + 4 * j]);
-            // pin the 16-byte read: left alone, the scheduler re-reads the window piecemeal with
-            // ds_read2_b32 at an 8-dword lane stride (8-way bank conflicts)
-            asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w));
-            w[4 * j] = q4.x;
-            w[4 * j + 1] = q4.y;
-            w[4 * j + 2] = q4.z;
-            w[4 * j + 3] = q4.w;
-        }
-        float acc[PER];
+        for (int r = 0; r < PER; ++r) acc[r] = v2f{0.f, 0.f};
+        v2f we[PER / 2], wo[PER / 2];
 #pragma unroll
-        for (int r = 0; r < PER; ++r) acc[r] = taps.g[H] * w[r];
-        // plain 81-tap FMAs: the symmetric form (one add per tap pair) saves no instruction and
-        // makes the scheduler hoist 320 pair sums into registers (256 VGPRs, 1 wave per SIMD)
+        for (int i = 0; i < PER / 2; ++i) we[i] = wpair(i);
 #pragma unroll
-        for (int j = 1; j <= 2 * H; ++j) {
-            const float gj = taps.g[j <= H ? H - j : j - H];
+        for (int i = 0; i < PER / 2; ++i) wo[i] = wpair(H + i);
 #pragma unroll
-            for (int r = 0; r < PER; ++r) acc[r] = fmaf(gj, w[r + j], acc[r]);
+        for (int i = 0; i < PER / 2; ++i) acc[2 * i + 1].x = taps.pair[0].x * we[i].y;   // t = 0 of odd r
+#pragma unroll
+        for (int j = 0; j <= H; ++j) {
+            const v2f tp = taps.pair[j];
+#pragma unroll
+            for (int i = 0; i < PER / 2; ++i) pk_fma_s(acc[2 * i], tp, we[i]);          // pairs j + i
+            if (j < H) {
+#pragma unroll
+                for (int i = 0; i < PER / 2; ++i) pk_fma_s_rev(acc[2 * i + 1], tp, wo[i]);   // pairs 40 - j + i
+#pragma unroll
+                for (int i = 0; i + 1 < PER / 2; ++i) we[i] = we[i + 1];
+                we[PER / 2 - 1] = wpair(j + PER / 2);
+#pragma unroll
+                for (int i = PER / 2 - 1; i > 0; --i) wo[i] = wo[i - 1];
+                wo[0] = wpair(H - 1 - j);
+            }
         }
         float4* dst = reinterpret_cast<float4*>(p_out + (int64_t)c * n + t0 + o);
-        dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        dst[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
+        dst[1] = make_float4(acc[4].x + acc[4].y, acc[5].x + acc[5].y, acc[6].x + acc[6].y, acc[7].x + acc[7].y);
         return;
     }
+    // edge tiles: odd reflection of m about the first / last sample (scipy filtfilt, padtype="odd")
+    auto tap = [&](int j) -> float {   // lag j >= 0
+        const v2f pr = taps.pair[(H + j) >> 1];
+        return ((H + j) & 1) ? pr.y : pr.x;
+    };
     const float m_first = (q0 <= 0) ? m_s[0 - q0] : 0.f;
     const float m_last = (last - q0 < T + 2 * H) ? m_s[last - q0] : 0.f;
     for (int r = 0; r < PER; ++r) {
-        const int64_t i = t0 + o + r;
-        if (i >= n) break;
-        float acc = taps.g[0] * m_s[o + r + H];
+        const int i = t0 + o + r;
+        if (i >= n32) break;
+        float acc = tap(0) * m_s[o + r + H];
         for (int j = 1; j <= H; ++j) {
-            const int64_t ql = i - j, qr = i + j;
+            const int ql = i - j, qr = i + j;
             const float el = (ql < 0) ? 2.f * m_first - m_s[-ql - q0] : m_s[ql - q0];
             const float er = (qr > last) ? 2.f * m_last - m_s[2 * last - qr - q0] : m_s[qr - q0];
-            acc = fmaf(taps.g[j], el + er, acc);
+            acc = fmaf(tap(j), el + er, acc);
         }
         p_out[(int64_t)c * n + i] = acc;
     }
@@ -676,10 +773,16 @@ void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipS
 void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
                             const float* g_host, float side_tap, hipStream_t stream) {
     if (batch <= 0) return;
-    PilotTaps taps;
-    for (int i = 0; i <= 40; ++i) taps.g[i] = g_host[i];
-    hipLaunchKernelGGL(k_pilot_stage_h40, grid2(n, kPilotFastTile, batch), dim3(kThreads), 0, stream, iq, m_out,
-                       p_out, n, taps, side_tap);
+    PilotTaps taps;   // h[t] = g[|t - 40|], t = 0..80, h[81] = 0
+    for (int j = 0; j <= 40; ++j) {
+        const int t0 = 2 * j, t1 = 2 * j + 1;
+        taps.pair[j].x = g_host[t0 >= 40 ? t0 - 40 : 40 - t0];
+        taps.pair[j].y = t1 <= 80 ? g_host[t1 >= 40 ? t1 - 40 : 40 - t1] : 0.f;
+    }
+    const unsigned tiles_x = (unsigned)((n + kPilotFastTile - 1) / kPilotFastTile);
+    const unsigned blocks = (tiles_x * (unsigned)batch + 7u) / 8u * 8u;
+    hipLaunchKernelGGL(k_pilot_stage_h40, dim3(blocks), dim3(kThreads), 0, stream, iq, m_out, p_out, n, taps,
+                       side_tap, tiles_x, (unsigned)batch);
     RC_LAUNCH_CHECK();
 }
 
