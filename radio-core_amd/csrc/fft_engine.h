@@ -26,6 +26,10 @@ constexpr int kFftTileW = 16;      // lines per tile: 16 x 8 B = one 128-byte se
 constexpr int kFftMaxStages = 8;
 constexpr int kFftMaxPasses = 4;
 constexpr int kFftMaxL = 512;      // longest in-LDS transform (tile + tables < 80 KiB: 2 workgroups per CU)
+// "Big" tiles (one 1024-thread workgroup per CU, tile up to 87 KiB of LDS): only where they save a
+// whole pass over the data -- lengths that need 4 passes of <= 512 but split into 3 of <= 640
+// (N = 2.4e8 = 600 x 625 x 640).  Plain load / store functors only.
+constexpr int kFftBigL = 640;
 
 // One pass.  Lines are indexed by (o1, o2, i): a tile covers 16 adjacent i.
 //   input  point l of a line: in [batch*in_batch  + o1*in_o1  + o2*in_o2  + i*in_i  + l*in_l ]

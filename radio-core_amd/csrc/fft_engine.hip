@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <vector>
 
@@ -38,6 +39,7 @@ bool is_fast_length(int64_t L) {
     switch (L) {
 #define RCFM_CASE(LEN, A, B, C, D) case LEN:
         RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+        RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
         return true;
         default: return false;
@@ -77,14 +79,19 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
                 const int64_t tiles = (extent + 15) / 16;
                 return (double)(tiles * 16) / (double)extent - 1.0;
             };
+            // 128-byte segments that straddle cache lines.  In-place passes: ~10 % slower (the lines they
+            // write are the ones they just read, still in L2).  Last pass (fresh lines): 1.75x slower when
+            // rows start at arbitrary 8-byte offsets (N = 240M with n_1 = 125), ~15 % when every row starts
+            // on a 64-byte boundary (n_1 = 600: two half-line writes).
+            auto straddle_write = [](int64_t extent) { return extent % 16 == 0 ? 0.0 : extent % 8 == 0 ? 0.5 : 2.0; };
             int64_t m = n;
             for (int i = 0; i < np - 1; ++i) {
                 m /= cur[i];
                 cost += 4.0 * tail(m);        // pass i tiles over j in [0, m_i)
-                if (m % 16) cost += 0.5;      // its 128-byte read segments straddle cache lines (~10 % slower)
+                if (m % 16) cost += 0.5;
             }
             cost += 4.0 * tail(cur[0]);       // the last pass tiles over k_1
-            if (cur[0] % 16) cost += 2.0;     // straddling WRITE segments: measured 1.75x slower (N = 240M)
+            cost += straddle_write(cur[0]);
             if (cost < best) {
                 best = cost;
                 ok = true;
@@ -102,9 +109,19 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
     return ok;
 }
 
+// RCFM_FFT_BIG=0 keeps every plan on <= 512-point tiles (A/B testing).
+bool big_tiles_enabled() {
+    static const bool v = [] {
+        const char* e = std::getenv("RCFM_FFT_BIG");
+        return !(e && e[0] == '0') && !fftk::getenv_generic_fft();   // the generic kernel stops at kFftMaxL
+    }();
+    return v;
+}
+
 }  // namespace
 
 bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* forced, int nforced) {
+    const bool default_cap = (max_l <= 0);
     if (max_l <= 0 || max_l > kFftMaxL) max_l = kFftMaxL;
     if (n < 256 || n >= (int64_t(1) << 32) || !smooth235(n)) return false;
     int np = 0;
@@ -113,7 +130,7 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
         if (nforced < 2 || nforced > kFftMaxPasses) return false;
         int64_t prod = 1;
         for (int i = 0; i < nforced; ++i) {
-            if (forced[i] < 16 || forced[i] > kFftMaxL) return false;
+            if (forced[i] < 16 || forced[i] > kFftBigL) return false;
             f[i] = forced[i];
             prod *= forced[i];
         }
@@ -121,6 +138,15 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
         np = nforced;
     } else {
         for (int cand = 2; cand <= kFftMaxPasses; ++cand) {
+            // three passes over big tiles beat four over regular ones (one read + write of the data less)
+            if (cand == 4 && default_cap && big_tiles_enabled() && split(n, 3, kFftBigL, f)) {
+                bool all_fast = true;
+                for (int i = 0; i < 3; ++i) all_fast = all_fast && is_fast_length(f[i]);
+                if (all_fast) {
+                    np = 3;
+                    break;
+                }
+            }
             if (split(n, cand, max_l, f)) {
                 np = cand;
                 break;
@@ -213,6 +239,22 @@ int FftEngine::compute_units() {
 }
 
 FftEngine::FftEngine(int64_t n) {
+    // RCFM_FFT_FORCE="f1,f2,..." (product n): pass lengths for plan experiments
+    if (const char* e = std::getenv("RCFM_FFT_FORCE")) {
+        int64_t f[kFftMaxPasses], prod = 1;
+        int nf = 0;
+        for (const char* c = e; *c && nf < kFftMaxPasses;) {
+            char* end = nullptr;
+            f[nf] = std::strtoll(c, &end, 10);
+            if (end == c) break;
+            prod *= f[nf++];
+            c = (*end == ',') ? end + 1 : end;
+        }
+        if (prod == n && fft_plan_describe(n, &desc_, 0, f, nf)) {
+            build_tables();
+            return;
+        }
+    }
     RC_REQUIRE(fft_plan_describe(n, &desc_), RCFM_ERR_ARG, "length not supported by the FFT engine");
     build_tables();
 }

@@ -1137,12 +1137,28 @@ struct StorePlainT {
     X(500, 10, 10, 5, 1)         \
     X(512, 8, 8, 8, 1)
 
+// Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.
+#define RCFM_FFT_BIG_LENGTHS(X) \
+    X(600, 10, 10, 6, 1)        \
+    X(625, 5, 5, 5, 5)          \
+    X(640, 10, 8, 8, 1)
+
 // Threads per tile.  Long tiles are LDS-limited to two workgroups per CU; 512 threads keep
 // 16 waves per CU in flight there (build with -DRCFM_FFT_LONG_THREADS=256 to compare).
 #ifndef RCFM_FFT_LONG_THREADS
 #define RCFM_FFT_LONG_THREADS 512
 #endif
-constexpr int tile_threads(int L) { return L >= 320 ? RCFM_FFT_LONG_THREADS : 256; }
+#ifndef RCFM_FFT_600_THREADS
+#define RCFM_FFT_600_THREADS 1024
+#endif
+constexpr int tile_threads(int L) {
+    return L == 600 ? RCFM_FFT_600_THREADS : L > kFftMaxL ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256;
+}
+
+// Big tiles are instantiated for the plain functors only (the streaming passes of long transforms).
+template <class T> struct is_plain_functor : std::false_type {};
+template <bool S> struct is_plain_functor<LoadPlainT<S>> : std::true_type {};
+template <bool S> struct is_plain_functor<StorePlainT<S>> : std::true_type {};
 
 // Which pass kinds a functor pair is ever used with (prunes template instantiations).
 enum PassKinds : int { kAnyPass = 0, kStridedOnly = 1, kRowsOnly = 2 };
@@ -1174,6 +1190,26 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
             RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
             default: break;
+        }
+        if constexpr (is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
+            switch (d.p.L) {
+#define RCFM_CASE(LEN, A, B, C, D)                                                                            \
+    case LEN:                                                                                                 \
+        if (rows) {                                                                                           \
+            if constexpr (KIND != kStridedOnly)                                                               \
+                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, true, tile_threads(LEN), LoadOp, StoreOp>), grid, \
+                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
+        } else {                                                                                              \
+            if constexpr (KIND != kRowsOnly)                                                                  \
+                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, false, tile_threads(LEN), LoadOp, StoreOp>), grid, \
+                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
+        }                                                                                                     \
+        done = true;                                                                                          \
+        break;
+                RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
+#undef RCFM_CASE
+                default: break;
+            }
         }
     }
     if (!done)

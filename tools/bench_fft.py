@@ -28,8 +28,11 @@ def main():
     hip.torch()
     cases = [(240000, 16, 20), (240000, 64, 10), (240000, 256, 5), (48000, 64, 20), (12500, 1024, 10),
              (10_000_000, 1, 10), (100_000_000, 1, 5), (240_000_000, 1, 5)]
-    if len(sys.argv) > 1:
-        cases = [c for c in cases if str(c[0]) in sys.argv[1:]]
+    if len(sys.argv) > 1:   # lengths from the command line (batch 1 unless n:batch)
+        cases = []
+        for a in sys.argv[1:]:
+            n, _, b = a.partition(":")
+            cases.append((int(n), int(b) if b else 1, 5))
     for n, batch, reps in cases:
         x = torch.view_as_complex(torch.randn(batch * n, 2, device="cuda"))
         y = torch.empty_like(x)
