@@ -38,7 +38,9 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
 // The same two stages for real signals transformed two at a time: U2 [ceil(count/2)][n] =
 // FFT(x[2c] + j x[2c+1]); the Hilbert load of channel c unpacks its own spectrum from U2.
 // U2 must not alias u (u is written while other channels still read their pair).
-// keep >= 0: only bins |k| <= keep of U2 are written.
+// keep >= 0: only bins |k| <= keep of U2 are written; kKeepLowerHalf: only bins 0 .. n/2 (all the packed
+// Hilbert chain below reads).
+constexpr int kKeepLowerHalf = -2;
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2* tmp, int count, int keep,
                          hipStream_t s);
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const float* m, float2* u, float2* tmp,
@@ -54,6 +56,7 @@ bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, c
 // The same chain with the PAIR kept packed through the inverse transform: w = IFFT(h U2) = z0 + j z1
 // (z_c = p_c + j Hilbert(p_c)), so Hilbert(p1) = p0 - Re w and Hilbert(p0) = Im w - p1: one inverse
 // transform per two channels; the mix reads p as well as m (k_fft_tile2_pair).
+bool fused_hilbert_packed_applies(const FftEngine& ei, const FftEngine& ef, int count);
 bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* p,
                                        const float* m, float2* tmp_i, float2* tmp_f, int count, hipStream_t s);
 void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,

@@ -305,12 +305,25 @@ struct MidStereoMixPair {
     }
 };
 
+// Stores bins k <= lo and k >= hi only.
 struct StorePruned {
     float2* out;
-    int n, keep;
+    int n, lo, hi;
+    StorePruned(float2* o, int n_, int keep) : out(o), n(n_) {
+        if (keep == kKeepLowerHalf) {   // one-sided users (Hilbert mask): bins 0 .. n/2
+            lo = n_ / 2;
+            hi = n_ + 1;
+        } else if (keep < 0) {
+            lo = n_;
+            hi = 0;
+        } else {                        // decimation: |k| <= keep
+            lo = keep;
+            hi = n_ - keep;
+        }
+    }
     __device__ __forceinline__ void operator()(const LineId& id, int, int64_t base, unsigned off, float2 v) const {
         const int k = (int)(base + off - (int64_t)id.batch * n);
-        if (keep < 0 || k <= keep || k >= n - keep) fftk::stream_store(out + base + off, v);
+        if (k <= lo || k >= hi) fftk::stream_store(out + base + off, v);
     }
 };
 
@@ -422,7 +435,7 @@ void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* 
     fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
     middle_passes(e, 1, np - 2, tmp, pairs, s);
     fftk::LoadPlainT<false> ldl{tmp};
-    if (keep >= 0) {
+    if (keep >= 0 || keep == kKeepLowerHalf) {
         StorePruned stl{U, (int)n, keep};
         fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), pairs, ldl, stl, s);
     } else {
@@ -464,6 +477,13 @@ bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, c
     RC_REQUIRE(fftk::launch_fft_tile2(d1, d2, count, ldl, mid, st1, s), RCFM_ERR_RUNTIME,
                "two-transform tile kernel refused a pair it should accept");
     return true;
+}
+
+bool fused_hilbert_packed_applies(const FftEngine& ei, const FftEngine& ef, int count) {
+    if (ei.npass() != 2 || ef.npass() != 2 || ei.desc().n != ef.desc().n) return false;
+    const int64_t n = ei.desc().n;
+    return fftk::fft_tile2_applies(ei.pass_dev(1, ei.tmp_stride(), n), ef.pass_dev(0, n, ef.tmp_stride()),
+                                   (count + 1) / 2);
 }
 
 bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* p,

@@ -573,7 +573,6 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
     constexpr int NW = (PER + HIST + 3) / 4;                       // float4 reads per thread
     __shared__ __attribute__((aligned(16))) float x_s[T + NW * 4];  // z[t0 - HIST + s]
     __shared__ float red[kThreads / 64];
-    __shared__ float tail_s[HIST], z_s[HIST], leg_s[CH];
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * T;
@@ -597,29 +596,30 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         const int64_t e = t0 - HIST + s;
         if (s < T + NW * 4) x_s[s] = (e >= 0 && e < total) ? v[it] : 0.f;
     }
-    if (dc != nullptr && tid < HIST) {
-        tail_s[tid] = tail_v;
-        z_s[tid] = z_v;
-    }
     __syncthreads();
     float mean = 0.f;
     if (dc != nullptr) {
-        if (tid < CH) {
-            // leg h = tid: its samples from the end are xc[total-1-(CH*i + (CH-1-h))], i = 0..49
-            const int A = (int)(total / CH);
-            const float2 d0 = dc[c];
-            const float S = (float)A * (tid == 0 ? d0.x : d0.y);
-            float acc = taps.b[0] * S, tl = 0.f, zsum = 0.f;
-            for (int j = 1; j <= 50; ++j) {
-                tl += tail_s[CH * (j - 1) + (CH - 1 - tid)];
-                acc = fmaf(taps.b[j], S - tl, acc);
-            }
-            for (int i = 0; i < 50; ++i) zsum += z_s[tid * 50 + i];
-            leg_s[tid] = acc + zsum;
+        // sum of the filter output = sum_legs (S_h B - sum_i tail_h[i] sfx[i + 1] + sum_i z_h[i]) with S_h the
+        // leg's input sum (from the DC bin), B = sum b, tail_h[i] its i-th input from the end, sfx[k] =
+        // sum_{j >= k} b[j], z_h the carried-in state.  One term per thread, one block reduction.
+        float term = 0.f;
+        if (tid < HIST) {
+            const int i = tid / CH;   // xc[total - 1 - tid] is the i-th sample from the end of its leg
+            float sf = 0.f;
+#pragma unroll
+            for (int j = 1; j <= 50; ++j) sf += (j > i) ? taps.b[j] : 0.f;
+            term = z_v - tail_v * sf;
         }
+        for (int off = 32; off > 0; off >>= 1) term += __shfl_down(term, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = term;
         __syncthreads();
-        float tot = 0.f;
-        for (int h = 0; h < CH; ++h) tot += leg_s[h];
+        float bsum = 0.f;
+#pragma unroll
+        for (int j = 0; j <= 50; ++j) bsum += taps.b[j];
+        const float2 d0 = dc[c];
+        const float legs = (CH == 2) ? d0.x + d0.y : d0.x;
+        float tot = (float)(total / CH) * legs * bsum;
+        for (int wv = 0; wv < kThreads / 64; ++wv) tot += red[wv];
         mean = tot / (float)total;
     }
     const int o = tid * PER;
