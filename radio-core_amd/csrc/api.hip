@@ -466,14 +466,11 @@ struct rcfm_demod_s {
                         fused_fft_pruned(*eng_B, Z, Z, T, cnt, std::min(A, B) / 2, s);
                     }
                 }
-                {
-                    StageTimer tm(ST_AUDIO_SPECTRUM, s);
-                    launch_stereo_unpack(Z, B, V, A, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
-                                         geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
-                }
-                {
+                {   // unpack + window + Nyquist rule ride on the first pass of IFFT_A
                     StageTimer tm(ST_IFFT_A, s);
-                    eng_A->c2c(V, V, TA, cnt, true, 1.0f, s);   // -> [cnt][A][2] float32, L/R interleaved
+                    fused_stereo_unpack_ifft(*eng_A, Z, B, V, TA, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
+                                             geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
+                    // -> [cnt][A][2] float32, L/R interleaved
                 }
                 float* st = state.as<float>() + (size_t)first * ch * 50;
                 run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true);

@@ -227,7 +227,8 @@ struct LineId {
     int64_t o1, o2, i;
 };
 
-// A LoadOp may need two input values per point (kFetches = 2: fetch + fetch2, post(id, l, a, b)).
+// A LoadOp may need two input values per point (kFetches = 2: fetch + fetch2, post(id, l, a, b)), or
+// two and a real coefficient (kFetches = 3: + float fetch3, post(id, l, a, b, c)).
 template <class T, class = void>
 struct fetch_count { static constexpr int value = 1; };
 template <class T>
@@ -242,7 +243,10 @@ struct has_ctx<T, std::void_t<decltype(T::kCtx)>> : std::true_type {};
 
 template <class LoadOp>
 __device__ __forceinline__ float2 load_now(const LoadOp& load, const LineId& id, int l, int64_t base, unsigned off) {
-    if constexpr (fetch_count<LoadOp>::value == 2)
+    if constexpr (fetch_count<LoadOp>::value == 3)
+        return load.post(id, l, load.fetch(id, l, base, off), load.fetch2(id, l, base, off),
+                         load.fetch3(id, l, base, off));
+    else if constexpr (fetch_count<LoadOp>::value == 2)
         return load.post(id, l, load.fetch(id, l, base, off), load.fetch2(id, l, base, off));
     else if constexpr (has_ctx<LoadOp>::value)
         return load.post(id, l, load.fetch(id, l, base, off), load.prepare(id));
@@ -512,7 +516,9 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     constexpr bool HZ = !ROWS && has_half_zones<LoadOp>::value && L % 2 == 0;
     auto zone = [](int q) -> int { return (q + 1) * m0 <= L / 2 ? 0 : (q * m0 > L / 2 ? 2 : 1); };
     float2 v[nld];
-    float2 v2[NF == 2 ? nld : 1];
+    float2 v2[NF >= 2 ? nld : 1];
+    float v3[NF == 3 ? nld : 1];
+    static_assert(NF <= 2 || !ROWS, "three-fetch load functors: strided passes only");
     if constexpr (ROWS) {
 #pragma unroll
         for (int it = 0; it < nld; ++it) {
@@ -546,8 +552,10 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
                     }
                 } else {
                     v[it * R0 + q] = load.fetch(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
-                    if constexpr (NF == 2)
+                    if constexpr (NF >= 2)
                         v2[it * R0 + q] = load.fetch2(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
+                    if constexpr (NF == 3)
+                        v3[it * R0 + q] = load.fetch3(id, l, in_base, (unsigned)l * in_l + (unsigned)wc);
                 }
             }
         }
@@ -626,7 +634,8 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
                         } else {
                             if (zone(q) != 2) x[q] = load.post(id, b + q * m0, x[q], zone(q));
                         }
-                    } else if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
+                    } else if constexpr (NF == 3) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q], v3[it * R0 + q]);
+                    else if constexpr (NF == 2) x[q] = load.post(id, b + q * m0, x[q], v2[it * R0 + q]);
                     else if constexpr (CTX) x[q] = load.post(id, b + q * m0, x[q], ctx);
                     else x[q] = load.post(id, b + q * m0, x[q]);
                 }

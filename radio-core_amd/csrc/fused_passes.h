@@ -62,6 +62,14 @@ bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef,
 void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,
                            hipStream_t s);
 
+// wbfm.py:86-87: audio decimation of both stereo legs.  U [count][B] = FFT_B of the packed signal (only
+// |k| <= A/2 is read); the unpacking into the packed Hermitian spectrum of l + j r, the Hamming weight and
+// the Nyquist rule of decimate.py:48 are the load of IFFT_A's first pass; out [count][A] = l + j r
+// (= float32 [count][A][2]).  dc (optional, [count]) receives (sum l, sum r) / A.  e is the length-A plan.
+void fused_stereo_unpack_ifft(const FftEngine& e, const float2* U, int64_t B, float2* out, float2* tmp, int count,
+                              const float* wr, int nyq, int nmin, float nyq_factor, float scale, float2* dc,
+                              hipStream_t s);
+
 // Forward FFT whose last pass stores only the bins |k| <= keep (decimation to A needs no more).
 void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,
                       hipStream_t s);

@@ -266,7 +266,7 @@ struct StoreStereoMix {
 
 // The same mix as the point-wise stage between two transforms (k_fft_tile2).
 struct MidStereoMix {
-    static constexpr bool kAux = true;
+    [[maybe_unused]] static constexpr bool kAux = true;
     const float* m;
     __device__ __forceinline__ float fetch_aux(const LineId&, int, int64_t base, unsigned off) const {
         return (m + base)[off];
@@ -302,6 +302,56 @@ struct MidStereoMixPair {
     __device__ __forceinline__ float2 second(const Keep& s2_1, float m1) const {
         const float lmr = (s2_1 * m1) * 1.0175f;
         return make_float2(m1 + lmr, m1 - lmr);
+    }
+};
+
+// wbfm.py:86-87 / decimate.py:48 as the load of IFFT_A's first pass: U = FFT_B of the packed signal
+// (m+lmr) + j(m-lmr), pruned to |k| <= A/2; point k of the packed Hermitian pair V = HL + j HR
+// (ifft(V) = l + j r), with the Hamming weight, truncation and Nyquist rule of scipy.signal.resample.
+struct LoadStereoUnpack {
+    static constexpr int kFetches = 3;
+    const float2* U;      // [count][B]
+    const float* wr;      // folded window, nyq entries
+    float2* dc;           // [count] or null: receives V[c][0] = (sum l, sum r) / A
+    int B, A, nyq, nmin;
+    float nyq_factor, scale;
+    int line_stride;
+    __device__ __forceinline__ int folded(int k) const { return k > A / 2 ? A - k : k; }
+    __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t, unsigned) const {
+        const int kk = folded(l * line_stride + (int)id.i);
+        return (U + (int64_t)id.batch * B)[kk < nyq ? kk : 0];
+    }
+    __device__ __forceinline__ float2 fetch2(const LineId& id, int l, int64_t, unsigned) const {
+        const int kk = folded(l * line_stride + (int)id.i);
+        return (U + (int64_t)id.batch * B)[(kk < nyq && kk > 0) ? B - kk : 0];
+    }
+    __device__ __forceinline__ float fetch3(const LineId& id, int l, int64_t, unsigned) const {
+        const int kk = folded(l * line_stride + (int)id.i);
+        return wr[kk < nyq ? kk : 0];
+    }
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 a, float2 b, float w0) const {
+        const int k = l * line_stride + (int)id.i;
+        const bool mirrored = k > A / 2;
+        const int kk = mirrored ? A - k : k;
+        float2 hl = make_float2(0.f, 0.f), hr = make_float2(0.f, 0.f);
+        if (kk < nyq) {
+            // u = l + j r with l, r real  =>  L[k] = (U[k] + conj U[-k]) / 2,  R[k] = (U[k] - conj U[-k]) / 2j
+            float w = w0 * scale;
+            if ((nmin & 1) == 0 && kk == nmin / 2) w *= nyq_factor;
+            hl = make_float2(0.5f * (a.x + b.x) * w, 0.5f * (a.y - b.y) * w);
+            hr = make_float2(0.5f * (a.y + b.y) * w, -0.5f * (a.x - b.x) * w);
+            if (kk == 0 || ((A & 1) == 0 && kk == A / 2)) {
+                hl.y = 0.f;
+                hr.y = 0.f;
+            }
+        }
+        if (mirrored) {
+            hl.y = -hl.y;
+            hr.y = -hr.y;
+        }
+        const float2 out = make_float2(hl.x - hr.y, hl.y + hr.x);
+        if (k == 0 && dc != nullptr) dc[id.batch] = out;   // one lane of one tile per channel
+        return make_float2(out.y, out.x);                  // swapped: inverse transform
     }
 };
 
@@ -519,6 +569,21 @@ void fused_fft_last_pruned(const FftEngine& e, const float2* tmp, float2* out, i
     fftk::LoadPlainT<false> ldl{tmp};
     StorePruned stl{out, (int)n, keep};
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
+}
+
+void fused_stereo_unpack_ifft(const FftEngine& e, const float2* U, int64_t B, float2* out, float2* tmp, int count,
+                              const float* wr, int nyq, int nmin, float nyq_factor, float scale, float2* dc,
+                              hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t A = e.desc().n;
+    const int np = e.npass();
+    LoadStereoUnpack ld{U, wr, dc, (int)B, (int)A, nyq, nmin, nyq_factor, scale, (int)e.desc().pass[0].in_l};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    fftk::StorePlainT<true> stl{out, 1.0f};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), A), count, ldl, stl, s);
 }
 
 void fused_fft_pruned(const FftEngine& e, const float2* in, float2* out, float2* tmp, int count, int keep,

@@ -570,31 +570,34 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
                                                     float* __restrict__ partial,
                                                     const float2* __restrict__ dc) {
     constexpr int T = kFirFastTile, PER = kFirPer, HIST = 50 * CH;
-    constexpr int NW = (PER + HIST + 3) / 4;                       // float4 reads per thread
-    __shared__ __attribute__((aligned(16))) float x_s[T + NW * 4];  // z[t0 - HIST + s]
+    constexpr int HP = (HIST + 3) / 4 * 4;                          // history rounded to whole 16-byte loads
+    constexpr int NW = (PER + HP) / 4;                              // float4 window reads per thread
+    constexpr int NV = (T + HP) / 4;                                // float4 loads per workgroup
+    __shared__ __attribute__((aligned(16))) float x_s[T + HP];      // z[t0 - HP + s]
     __shared__ float red[kThreads / 64];
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * T;
     const float* xc = x + (int64_t)c * total;
     float* yc = y + (int64_t)c * total;
-    constexpr int NL = (T + HIST + kThreads - 1) / kThreads;
-    float v[NL];
+    constexpr int NL = (NV + kThreads - 1) / kThreads;
+    float4 v[NL];
     float tail_v = 0.f, z_v = 0.f;
     if (dc != nullptr && tid < HIST) {                              // last 50 inputs of each leg + state
         tail_v = xc[total - 1 - tid];                               // interleaved: leg = (total-1-tid) % CH
         z_v = state[(int64_t)c * HIST + tid];
     }
 #pragma unroll
-    for (int it = 0; it < NL; ++it) {                              // unconditional, clamped loads
-        const int64_t e = t0 - HIST + tid + kThreads * it;
-        v[it] = xc[e < 0 ? 0 : (e > total - 1 ? total - 1 : e)];
+    for (int it = 0; it < NL; ++it) {                              // unconditional, clamped 16-byte loads
+        const int64_t e = t0 - HP + 4 * (int64_t)(tid + kThreads * it);   // total % 4 == 0: whole quads are in or out
+        v[it] = *reinterpret_cast<const float4*>(xc + (e < 0 ? 0 : (e > total - 4 ? total - 4 : e)));
     }
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
-        const int s = tid + kThreads * it;
-        const int64_t e = t0 - HIST + s;
-        if (s < T + NW * 4) x_s[s] = (e >= 0 && e < total) ? v[it] : 0.f;
+        const int q = tid + kThreads * it;
+        const int64_t e = t0 - HP + 4 * (int64_t)q;
+        if (q < NV)
+            *reinterpret_cast<float4*>(&x_s[4 * q]) = (e >= 0 && e < total) ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float mean = 0.f;
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
 #pragma unroll
     for (int j = 0; j <= 50; ++j) {
 #pragma unroll
-        for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], w[r + HIST - CH * j], acc[r]);
+        for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], w[r + HP - CH * j], acc[r]);
     }
     float local = 0.f;
     const int64_t e0 = t0 + o;

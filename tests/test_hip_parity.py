@@ -123,6 +123,29 @@ def test_run_all_equals_per_channel_loop(rc, oracle):
             assert rel_err(audio[ch.index], want) <= TOL, (buf, ch.index)
 
 
+def test_narrow_channels_take_the_haloed_gather(rc, oracle):
+    """Channels much narrower than the band (cfg4's shape, scaled down): the tuner's gather reads the
+    haloed spectrum without wrap-around and windows by the cosine series.  The centre channel straddles
+    bin 0 (negative bins come from the left halo), odd channel count -> a lone last pair."""
+    N, B, A, C = 6_000_000, 60000, 12000, 5
+    centres = workloads.channel_grid(C, 75000)
+    tuner = rc.Tuner()
+    ref = oracle.Tuner()
+    for f in centres:
+        tuner.add_channel(f, B, rc.WBFM(B, A))
+        ref.add_channel(f, B, oracle.WBFM(B, A))
+    tuner.request_bandwidth(float(N))
+    ref.request_bandwidth(float(N))
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.35)
+    tuner.load(x)
+    ref.load(x)
+    audio = tuner.run_all()
+    for ch in ref.channels():
+        iq = ref.run_pruned(ch.index)
+        assert rel_err(tuner.run(ch.index), iq) <= TOL, ch.index
+        assert rel_err(audio[ch.index], ch.demodulator.run(iq)[0]) <= TOL, ch.index
+
+
 def test_tuner_spectrum_bins(rc, golden):
     """Tuner.load keeps FFT_N(x): spot bins against the reference's."""
     g = golden("tuner")
