@@ -222,18 +222,34 @@ def main():
     demod = ctypes.c_void_p()
     kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
     hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
-    audio = torch.empty((mine, A, ch), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((C, A, ch), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+    # N > 1: the audio blocks are double-buffered so that the gather of buffer i (RCCL's own stream, xGMI)
+    # overlaps the kernels of buffer i+1; every gather completes inside the timed region (barrier()).
+    nbuf = 2 if world > 1 else 1
+    audios = [torch.empty((mine, A, ch), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+    audio = audios[0]
+    gathereds = [torch.empty((C, A, ch), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+                 for _ in range(nbuf)]
+    in_flight = [None] * nbuf
+    counter = [0]
 
     def step():
         s = hip.stream()
+        slot = counter[0] % nbuf
+        counter[0] += 1
+        if in_flight[slot] is not None:
+            in_flight[slot].wait()          # stream-ordered: this slot's previous block has left
+            in_flight[slot] = None
         hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
         # pipeline_run addresses channels of tuner and demod by the same index
-        hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), s))
-        if world > 1:
-            sharding.gather_audio(audio, C, dst=0, out=gathered)   # RCCL over xGMI: the only collective on the path
+        hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audios[slot]), s))
+        if world > 1:                       # RCCL over xGMI: the only collective on the path
+            in_flight[slot] = sharding.gather_audio(audios[slot], C, dst=0, out=gathereds[slot], async_op=True)
 
     def barrier():
+        for i in range(nbuf):
+            if in_flight[i] is not None:
+                in_flight[i].wait()
+                in_flight[i] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -10,7 +10,7 @@ The reference has no multi-device code at all; its per-channel loop is
 examples/multi_fm_server.py:100-106.
 """
 
-__all__ = ["channel_range", "channel_counts", "gather_audio"]
+__all__ = ["channel_range", "channel_counts", "gather_audio", "GatherHandle"]
 
 
 def channel_range(rank, world, channels):
@@ -24,7 +24,22 @@ def channel_counts(world, channels):
     return [channel_range(r, world, channels)[1] - channel_range(r, world, channels)[0] for r in range(world)]
 
 
-def gather_audio(local, channels, dst=0, group=None, out=None):
+class GatherHandle:
+    """A gather in flight (gather_audio(..., async_op=True)).  wait() orders the caller's stream (RCCL)
+    or thread (gloo) after the collective and returns what gather_audio would have returned."""
+
+    def __init__(self, work, finish):
+        self._work = work
+        self._finish = finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish()
+
+
+def gather_audio(local, channels, dst=0, group=None, out=None, async_op=False):
     """Gather per-rank audio [C_r, A, ch] to `dst`; returns [C, A, ch] there, None elsewhere.
 
     `out` (on `dst`, shape [C, A, ch]) receives the blocks in place when every rank owns the
@@ -32,11 +47,15 @@ def gather_audio(local, channels, dst=0, group=None, out=None):
 
     torch.distributed.gather needs equally sized blocks; when C is not divisible by G the
     shorter blocks are padded to the longest one and trimmed on arrival.
+
+    async_op=True returns a GatherHandle at once: the collective runs on RCCL's own stream behind
+    the work already queued on the caller's stream, so buffer i can travel over xGMI while the
+    kernels of buffer i+1 run (`local` and `out` must stay untouched until wait()).
     """
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local
+        return GatherHandle(None, lambda: local) if async_op else local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = channel_counts(world, channels)
@@ -55,13 +74,17 @@ def gather_audio(local, channels, dst=0, group=None, out=None):
         else:
             recv = [torch.empty((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
                     for _ in range(world)]
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    if even and out is not None:
-        return out
-    full = torch.cat([blk[:c] for blk, c in zip(recv, counts)], dim=0)
-    if out is not None:
-        out.copy_(full)
-        return out
-    return full
+    work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
+
+    def finish():
+        if rank != dst:
+            return None
+        if even and out is not None:
+            return out
+        full = torch.cat([blk[:c] for blk, c in zip(recv, counts)], dim=0)
+        if out is not None:
+            out.copy_(full)
+            return out
+        return full
+
+    return GatherHandle(work, finish) if async_op else finish()

@@ -54,6 +54,12 @@ def _worker(rank, world, port, result_path):
     lo, hi = sharding.channel_range(rank, world, len(CENTRES))
     local = torch.from_numpy(_audio_for(range(lo, hi)))
     full = sharding.gather_audio(local, len(CENTRES), dst=0)
+    # the overlapped form bench.py uses (buffer i travels while buffer i+1 is computed): same result
+    handle = sharding.gather_audio(local, len(CENTRES), dst=0, async_op=True)
+    again = handle.wait()
+    assert (again is None) == (full is None)
+    if full is not None:
+        assert torch.equal(again, full)
     dist.barrier()
     if rank == 0:
         np.save(result_path, full.numpy())
