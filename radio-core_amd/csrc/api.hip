@@ -438,20 +438,39 @@ struct rcfm_demod_s {
                 float2* T = buf_T.as<float2>();
                 float2* TA = buf_TA.as<float2>();
                 float2* U2 = buf_U2.as<float2>();
-                static const bool unpacked = std::getenv("RCFM_HILBERT_UNPACK") != nullptr;   // A/B
+                // RCFM_PILOT_CHAIN=0: pair FFT -> U2 -> masked IFFT as separate transforms; RCFM_HILBERT_UNPACK=1:
+                // additionally one inverse FFT per channel (A/B testing of the fused forms)
+                static const bool unpacked = std::getenv("RCFM_HILBERT_UNPACK") != nullptr;
+                static const bool no_chain = [] {
+                    const char* e = std::getenv("RCFM_PILOT_CHAIN");
+                    return e && e[0] == '0';
+                }();
+                const bool chain = eng_Bi && !unpacked && !no_chain && fused_pilot_chain_applies(*eng_B, *eng_Bi, cnt);
                 const bool packed = eng_Bi && !unpacked && fused_hilbert_packed_applies(*eng_Bi, *eng_B, cnt);
-                {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
-                    StageTimer tm(ST_FFT_REAL_B, s);
-                    fused_real_pair_fft(*eng_B, p, U2, T, cnt, packed ? kKeepLowerHalf : -1, s);
-                }
                 bool paired = false;
-                if (eng_Bi) {
-                    // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
-                    // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
-                    StageTimer tm(ST_IFFT_B, s);
-                    paired = !packed ? fused_hilbert_pair_ifft_mix_fft(*eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s)
-                                      : fused_hilbert_packed_ifft_mix_fft(*eng_Bi, *eng_B, U2, p, m,
-                                                                          buf_Ti.as<float2>(), T, cnt, s);
+                if (chain) {
+                    {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
+                        StageTimer tm(ST_FFT_REAL_B, s);
+                        fused_pilot_chain_fft_first(*eng_B, p, T, cnt, s);
+                    }
+                    {   // ... last pass, one-sided mask, inverse FFT, stereo matrix, first pass of the packed L/R FFT
+                        StageTimer tm(ST_IFFT_B, s);
+                        fused_pilot_chain_mask_mix(*eng_B, *eng_Bi, p, m, T, buf_Ti.as<float2>(), cnt, s);
+                    }
+                    paired = true;
+                } else {
+                    {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
+                        StageTimer tm(ST_FFT_REAL_B, s);
+                        fused_real_pair_fft(*eng_B, p, U2, T, cnt, packed ? kKeepLowerHalf : -1, s);
+                    }
+                    if (eng_Bi) {
+                        // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
+                        // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
+                        StageTimer tm(ST_IFFT_B, s);
+                        paired = !packed ? fused_hilbert_pair_ifft_mix_fft(*eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s)
+                                         : fused_hilbert_packed_ifft_mix_fft(*eng_Bi, *eng_B, U2, p, m,
+                                                                             buf_Ti.as<float2>(), T, cnt, s);
+                    }
                 }
                 if (paired) {
                     StageTimer tm(ST_FFT_B, s);

@@ -59,6 +59,17 @@ bool fused_hilbert_pair_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, c
 bool fused_hilbert_packed_applies(const FftEngine& ei, const FftEngine& ef, int count);
 bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef, const float2* U2, const float* p,
                                        const float* m, float2* tmp_i, float2* tmp_f, int count, hipStream_t s);
+// The whole pilot chain of WBFM (wbfm.py:80-87) in three launches when ef = (n_1, n_2) and ei = (n_2, n_1)
+// are the two two-pass plans of one length:  (1) first pass of the pair FFT of p (two channels per complex
+// signal);  (2) its last pass + scipy.signal.hilbert's mask + the first pass of the inverse FFT on one
+// tile (k_fft_tile2): the pair spectrum never reaches memory;  (3) the inverse FFT's last pass + split
+// into the two analytic signals + stereo mix + first pass of each member's packed L/R FFT
+// (k_fft_tile2_pair).  Leaves ef's scratch tmp_f ready for fused_fft_last_pruned.
+bool fused_pilot_chain_applies(const FftEngine& ef, const FftEngine& ei, int count);
+void fused_pilot_chain_fft_first(const FftEngine& ef, const float* p, float2* tmp_f, int count, hipStream_t s);
+void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const float* p, const float* m,
+                                float2* tmp_f, float2* tmp_i, int count, hipStream_t s);
+
 void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,
                            hipStream_t s);
 

@@ -276,6 +276,23 @@ struct MidStereoMix {
     }
 };
 
+// scipy.signal.hilbert's mask as the point-wise stage between the pair FFT's last pass and the masked
+// inverse FFT's first pass (k_fft_tile2): bin = k * stride + i; the value leaves swapped and scaled for the
+// inverse transform.  No auxiliary input.
+struct MidHilbertMask {
+    [[maybe_unused]] static constexpr bool kAux = true;
+    int n, stride;
+    float scale;
+    __device__ __forceinline__ float fetch_aux(const LineId&, int, int64_t, unsigned) const { return 0.f; }
+    __device__ __forceinline__ float2 operator()(const LineId& id, int k, float2 v, float) const {
+        const int bin = k * stride + (int)id.i;
+        float h = (bin == 0) ? scale : 2.f * scale;
+        if (bin >= (n + 1) / 2) h = 0.f;
+        if ((n & 1) == 0 && bin == n / 2) h = scale;
+        return make_float2(v.y * h, v.x * h);
+    }
+};
+
 // The same mix for PAIRS of channels whose pilots went through one complex transform
 // (k_fft_tile2_pair): U2 = FFT(p0 + j p1), w = IFFT(h U2) = z0 + j z1 with z_c = p_c + j H_c, so
 // H1 = p0 - Re w and H0 = Im w - p1: one masked inverse FFT yields both analytic signals.
@@ -560,6 +577,47 @@ bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef,
     RC_REQUIRE(fftk::launch_fft_tile2_pair(d1, d2, count, ldl, mid, st1, s), RCFM_ERR_RUNTIME,
                "two-transform pair kernel refused a pair it should accept");
     return true;
+}
+
+bool fused_pilot_chain_applies(const FftEngine& ef, const FftEngine& ei, int count) {
+    if (ei.npass() != 2 || ef.npass() != 2 || ei.desc().n != ef.desc().n) return false;
+    const int64_t n = ef.desc().n;
+    const int pairs = (count + 1) / 2;
+    return fftk::fft_tile2_applies(ef.pass_dev(1, ef.tmp_stride(), n), ei.pass_dev(0, n, ei.tmp_stride()), pairs) &&
+           fftk::fft_tile2_applies(ei.pass_dev(1, ei.tmp_stride(), n), ef.pass_dev(0, n, ef.tmp_stride()), pairs);
+}
+
+void fused_pilot_chain_fft_first(const FftEngine& ef, const float* p, float2* tmp_f, int count, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = ef.desc().n;
+    LoadRealPair ld{p, (int)n, count};
+    fftk::StorePlainT<false> st0{tmp_f, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(ef.pass_dev(0, 0, ef.tmp_stride()), (count + 1) / 2, ld, st0, s);
+}
+
+void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const float* p, const float* m,
+                                float2* tmp_f, float2* tmp_i, int count, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = ef.desc().n;
+    const int pairs = (count + 1) / 2;
+    {   // pair FFT last pass -> mask -> inverse FFT first pass: the pair spectrum never reaches memory
+        const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), n);
+        const FftPassDev d2 = ei.pass_dev(0, n, ei.tmp_stride());
+        fftk::LoadPlainT<false> ld{tmp_f};
+        MidHilbertMask mid{(int)n, (int)d1.p.out_k, (float)(1.0 / (double)n)};
+        fftk::StorePlainT<false> st{tmp_i, 1.0f};
+        RC_REQUIRE(fftk::launch_fft_tile2(d1, d2, pairs, ld, mid, st, s), RCFM_ERR_RUNTIME,
+                   "two-transform tile kernel refused a pair it should accept");
+    }
+    {   // inverse FFT last pass -> split + stereo mix -> packed L/R FFT first pass, per member of the pair
+        const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);
+        const FftPassDev d2 = ef.pass_dev(0, n, ef.tmp_stride());
+        fftk::LoadPlainT<false> ld{tmp_i};
+        MidStereoMixPair mid{p, m};
+        fftk::StorePlainT<false> st{tmp_f, 1.0f};
+        RC_REQUIRE(fftk::launch_fft_tile2_pair(d1, d2, count, ld, mid, st, s), RCFM_ERR_RUNTIME,
+                   "two-transform pair kernel refused a pair it should accept");
+    }
 }
 
 void fused_fft_last_pruned(const FftEngine& e, const float2* tmp, float2* out, int count, int keep, hipStream_t s) {
