@@ -326,6 +326,7 @@ struct rcfm_demod_s {
     ResampleGeom geom;   // B -> A, real, Hamming
     PlanCache r2c_B, c2c_inv_B, c2c_fwd_B, c2c_inv_A, c2r_A;
     std::unique_ptr<FftEngine> eng_B, eng_A;   // both set: the engine path with fused passes
+    std::unique_ptr<FftEngine> eng_Ad;         // length A as (A / n_1, n_1): its first pass tiles like eng_B's last
     std::unique_ptr<FftEngine> eng_Bi;         // eng_B's two pass lengths swapped (k_fft_tile2 pairing)
     DeviceBuffer buf_Ti;
     DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2, buf_dc;
@@ -363,6 +364,14 @@ struct rcfm_demod_s {
                     const int64_t swapped[2] = {pd.pass[1].L, pd.pass[0].L};
                     eng_Bi = std::make_unique<FftEngine>(B, swapped, 2);
                     buf_Ti.reset(c * eng_Bi->tmp_stride() * sizeof(float2));
+                    // decimation between FFT_B's last pass and IFFT_A's first (fused_passes.h)
+                    const int64_t n1 = pd.pass[0].L;
+                    const int64_t fa[2] = {A / n1, n1};
+                    FftPlanDesc pa;
+                    if (A < B && A % (2 * n1) == 0 && fft_plan_describe(A, &pa, 0, fa, 2)) {
+                        eng_Ad = std::make_unique<FftEngine>(A, fa, 2);
+                        buf_TA.reserve(c * eng_Ad->tmp_stride() * sizeof(float2));
+                    }
                 }
             }
             if (kind != RCFM_WBFM) {
@@ -471,6 +480,19 @@ struct rcfm_demod_s {
                                          : fused_hilbert_packed_ifft_mix_fft(*eng_Bi, *eng_B, U2, p, m,
                                                                              buf_Ti.as<float2>(), T, cnt, s);
                     }
+                }
+                static const bool no_decim = [] {
+                    const char* e = std::getenv("RCFM_DECIM_TILE");
+                    return e && e[0] == '0';
+                }();
+                if (paired && eng_Ad && !no_decim && fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, cnt)) {
+                    // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
+                    StageTimer tm(ST_FFT_B, s);
+                    fused_fft_decim_ifft(*eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
+                                         buf_dc.as<float2>(), s);
+                    float* st = state.as<float>() + (size_t)first * ch * 50;
+                    run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true);
+                    return;
                 }
                 if (paired) {
                     StageTimer tm(ST_FFT_B, s);

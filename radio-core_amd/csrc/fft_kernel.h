@@ -1069,6 +1069,183 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
     second_transform(out_base1);
 }
 
+// ---- a long forward transform's last pass feeding a short inverse transform's first pass --------
+//
+// Spectral decimation B -> A (scipy.signal.resample) between two transforms on one tile.  Plan
+// (n_1, L) of length B ends with rows tiles of 16 lines k_0 x L outputs k_1 (bin k = k_0 + n_1 k_1); when
+// A = n_1 L2 (L2 even), the bins that survive the decimation, |k| <= A/2, are rows k_1 < L2/2 and
+// k_1 > L - L2/2 (+ the two Nyquist rows) of the SAME lines, and bin kappa = k_0 + n_1 l of the short
+// spectrum is row l of a strided first pass of plan (L2, n_1) of length A.  So: transform 1 (L points),
+// keep L2 rows (the two Nyquist rows merge in line k_0 = 0), weight them (WinOp), transform 2 (L2
+// points, inverse by the swap identity).  The long spectrum never reaches memory.
+//
+// WinOp contract: float weight(id, l, k0) (issued with the tile's loads), void dc_bin(id, float2 v0) receives
+// the weighted bin kappa = 0.
+template <int L, int R0, int R1, int R2, int R3, int L2, int Q0, int Q1, int T, class LoadOp, class WinOp, class StoreOp>
+__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPassDev d1, FftPassDev d2, LoadOp load,
+                                                                           WinOp win, StoreOp store) {
+    constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
+    static_assert(Q0 * Q1 == L2 && L2 % 2 == 0 && L2 < L, "bad short transform");
+    constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;
+    constexpr int RG = T / W;
+    constexpr int nld = (L * W + T - 1) / T;
+    constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
+    constexpr int nwin = (L2 * W + T - 1) / T;          // weighting sweep: points per thread
+    __shared__ __attribute__((aligned(16))) float2 tile[L * kRowsPitch];
+    __shared__ __attribute__((aligned(16))) float2 tw[L];
+    const FftPass& p1 = d1.p;
+    const FftPass& p2 = d2.p;
+    const int tid = threadIdx.x;
+    const int w = tid & (W - 1), rg = tid >> 4;
+
+    LineId id;
+    id.batch = blockIdx.z;
+    id.o1 = 0;
+    id.o2 = 0;
+    const int i0 = (int)tile_of_block() * W;
+    const int left = (int)p1.n_inner - i0;
+    const int wvalid = left < W ? left : W;
+    const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
+    const int64_t out_base = (int64_t)id.batch * d2.out_batch + i0;
+    const unsigned in_i = (unsigned)p1.in_i, out_k = (unsigned)p2.out_k;
+
+    auto kbase = [](int g) -> int {
+        if constexpr (S == 2) {
+            return g;
+        } else if constexpr (S == 3) {
+            constexpr int w1 = L / (R0 * RL);
+            const int q1 = g / w1, q2 = g - q1 * w1;
+            return q1 + R0 * q2;
+        } else {
+            constexpr int w1 = L / (R0 * RL), w2 = L / (R0 * R1 * RL);
+            const int q1 = g / w1, r1 = g - q1 * w1;
+            const int q2 = r1 / w2, q3 = r1 - q2 * w2;
+            return q1 + R0 * (q2 + R1 * q3);
+        }
+    };
+
+    // ---- loads: the tile and the weights of the rows that survive -------------------------------
+    float2 v[nld];
+#pragma unroll
+    for (int it = 0; it < nld; ++it) {
+        int e = tid + T * it;
+        if ((L * W) % T != 0) e = e < L * W ? e : 0;
+        const int wl = e / L, l = e - wl * L;
+        const int wcl = wl < wvalid ? wl : 0;
+        id.i = i0 + wcl;
+        v[it] = load.fetch(id, l, in_base, (unsigned)wcl * in_i + (unsigned)l);
+    }
+    float wgt[nwin];
+#pragma unroll
+    for (int it = 0; it < nwin; ++it) {
+        int e = tid + T * it;
+        if ((L2 * W) % T != 0) e = e < L2 * W ? e : 0;
+        const int wl = e & (W - 1);
+        wgt[it] = win.weight(id, e >> 4, i0 + (wl < wvalid ? wl : 0));
+    }
+    for (int e = tid; e < L; e += T) tw[e] = d1.stage_tw[e];
+#pragma unroll
+    for (int it = 0; it < nld; ++it) {
+        const int e = tid + T * it;
+        const int wl = e / L, l = e - wl * L;
+        id.i = i0 + wl;
+        const float2 x = load.post(id, l, v[it]);
+        if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
+    }
+    __syncthreads();
+    stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+    __syncthreads();
+    if constexpr (S >= 3) {
+        stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+    if constexpr (S >= 4) {
+        stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
+        __syncthreads();
+    }
+
+    // ---- last stage of transform 1; the surviving rows land in natural order -------------------
+    float2 xr[nitL * RL];
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+#pragma unroll
+            for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
+            dft_p<RL>(&xr[it * RL]);
+        }
+    }
+    __syncthreads();   // every slot has been read
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const int k = kb + (L / RL) * q;
+                // row of the short spectrum: positive frequencies, negative frequencies, the negative
+                // Nyquist row (kept by every line), the positive one (parked in row L2: only bin A/2 of
+                // line k_0 = 0 needs it)
+                int l = -1;
+                if (k < L2 / 2) l = k;
+                else if (k >= L - L2 / 2) l = k - (L - L2);
+                else if (k == L2 / 2) l = L2;
+                if (l >= 0) tile[lds_slot<true>(l, w)] = xr[it * RL + dft_slot<RL>(q)];
+            }
+        }
+    }
+    for (int e = tid; e < L2; e += T) tw[e] = d2.stage_tw[e];   // (every read of transform 1's table is done)
+    __syncthreads();
+
+    // ---- weights, Nyquist merge, swap for the inverse transform ----------------------------------
+#pragma unroll
+    for (int it = 0; it < nwin; ++it) {
+        const int e = tid + T * it;
+        if ((L2 * W) % T == 0 || e < L2 * W) {
+            const int l = e >> 4, wl = e & (W - 1);
+            float2 x = tile[lds_slot<true>(l, wl)];
+            if (l == L2 / 2 && i0 + wl == 0) {   // Y[A/2] = X[A/2] + X[-A/2] (one point of one tile)
+                const float2 y = tile[lds_slot<true>(L2, wl)];
+                x = make_float2(x.x + y.x, x.y + y.y);
+            }
+            x = make_float2(x.x * wgt[it], x.y * wgt[it]);
+            if (l == 0 && i0 + wl == 0) {
+                id.i = 0;
+                win.dc_bin(id, x);
+            }
+            tile[lds_slot<true>(l, wl)] = make_float2(x.y, x.x);
+        }
+    }
+    __syncthreads();
+
+    // ---- transform 2: a strided pass of the short plan whose input sits in LDS ---------------------
+    stage_lds<L2, Q0, L2, true, RG>(tile, tw, w, rg);
+    __syncthreads();
+    constexpr int rows2 = L2 / Q1;
+    static_assert(rows2 <= RG, "short transform: one sweep");
+    id.i = i0 + w;
+    const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
+    if (rg < rows2) {
+        float2 x[Q1];
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) x[q] = tile[lds_slot<true>(rg * Q1 + q, w)];
+        dft_p<Q1>(x);
+        const float2 D = big_twiddle(d2, f * (unsigned)(L2 / Q1));
+        float2 Tw = big_twiddle(d2, f * (unsigned)rg);
+        if (w < wvalid) {
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                const int k = rg + (L2 / Q1) * q;
+                const float2 y = cmul(x[dft_slot<Q1>(q)], Tw);
+                Tw = cmul(Tw, D);
+                store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
+            }
+        }
+    }
+}
+
 // ---- plain functors ------------------------------------------------------------
 // SWAP = exchange re/im: the inverse transform by the swap identity ifft(x) = swap(fft(swap(x))).
 
@@ -1242,6 +1419,39 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
     return fast && !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L &&
            d1.p.n_inner == d2.p.n_inner && d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 &&
            d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
+}
+
+// Spectral decimation between two transforms (k_fft_tile2_decim): (long last-pass length, short
+// first-pass length) pairs with an instantiation.
+#define RCFM_FFT_DECIM_PAIRS(X) X(500, 10, 10, 5, 1, 100, 10, 10)
+
+inline bool fft_tile2_decim_applies(const FftPassDev& d1, const FftPassDev& d2, int batch) {
+    bool fast = false;
+#define RCFM_CASE(LEN, A, B, C, D, LEN2, E, F) fast = fast || (d1.p.L == LEN && d2.p.L == LEN2);
+    RCFM_FFT_DECIM_PAIRS(RCFM_CASE)
+#undef RCFM_CASE
+    return fast && !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l &&
+           d1.p.n_inner == d2.p.n_inner && d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 &&
+           d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
+}
+
+template <class LoadOp, class WinOp, class StoreOp>
+inline bool launch_fft_tile2_decim(const FftPassDev& d1, const FftPassDev& d2, int batch, const LoadOp& ld,
+                                   const WinOp& win, const StoreOp& st, hipStream_t s) {
+    if (!fft_tile2_decim_applies(d1, d2, batch)) return false;
+    const dim3 grid((unsigned)((d1.p.n_inner + W - 1) / W), 1, (unsigned)batch);
+    bool done = false;
+#define RCFM_CASE(LEN, A, B, C, D, LEN2, E, F)                                                                   \
+    if (!done && d1.p.L == LEN && d2.p.L == LEN2) {                                                             \
+        hipLaunchKernelGGL((k_fft_tile2_decim<LEN, A, B, C, D, LEN2, E, F, tile_threads(LEN), LoadOp, WinOp, StoreOp>), \
+                           grid, dim3(tile_threads(LEN)), 0, s, d1, d2, ld, win, st);                           \
+        done = true;                                                                                            \
+    }
+    RCFM_FFT_DECIM_PAIRS(RCFM_CASE)
+#undef RCFM_CASE
+    if (!done) return false;
+    RC_HIP(hipGetLastError());
+    return true;
 }
 
 // The pair form: `count` member signals, ceil(count / 2) first transforms.

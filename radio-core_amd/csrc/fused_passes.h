@@ -73,6 +73,14 @@ void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const 
 void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,
                            hipStream_t s);
 
+// wbfm.py:86-87 without the long spectrum: the packed L/R FFT's last pass (plan ef = (n_1, L) of length B,
+// scratch tmp_f from the pilot chain), the decimation to A = n_1 L2 (window, truncation, Nyquist merge,
+// decimate.py:48) and the first pass of IFFT_A (plan ea = (L2, n_1)) on one tile (k_fft_tile2_decim), then
+// ea's last pass.  out [count][A] = l + j r (= float32 [count][A][2]); dc as below.
+bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int count);
+void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float2* out, float2* tmp_a,
+                          int count, const float* wr, float scale, float2* dc, hipStream_t s);
+
 // wbfm.py:86-87: audio decimation of both stereo legs.  U [count][B] = FFT_B of the packed signal (only
 // |k| <= A/2 is read); the unpacking into the packed Hermitian spectrum of l + j r, the Hamming weight and
 // the Nyquist rule of decimate.py:48 are the load of IFFT_A's first pass; out [count][A] = l + j r

@@ -372,6 +372,26 @@ struct LoadStereoUnpack {
     }
 };
 
+// decimate.py:48 for the packed stereo pair between FFT_B's last pass and IFFT_A's first pass
+// (k_fft_tile2_decim): u = l + j r is one complex signal and the Hamming weight is real and even, so
+// resampling u resamples both legs: V[kappa] = U[k] W[|kappa|] / B with scipy's Nyquist merge -- no
+// unpacking into L and R at all.
+struct WinAudioDecim {
+    const float* wr;   // folded window, A/2 + 1 entries
+    float2* dc;        // [count] or null: receives V[c][0] = (sum l, sum r) / A
+    float scale;
+    int A, n1;
+    __device__ __forceinline__ float weight(const LineId&, int l, int k0) const {
+        const int kappa = l * n1 + k0;
+        int kk = kappa <= A / 2 ? kappa : A - kappa;
+        kk = kk < 0 ? 0 : kk;   // rows past the tile's real extent (clamped lanes)
+        return wr[kk] * scale;
+    }
+    __device__ __forceinline__ void dc_bin(const LineId& id, float2 v) const {
+        if (dc != nullptr) dc[id.batch] = v;
+    }
+};
+
 // Stores bins k <= lo and k >= hi only.
 struct StorePruned {
     float2* out;
@@ -627,6 +647,28 @@ void fused_fft_last_pruned(const FftEngine& e, const float2* tmp, float2* out, i
     fftk::LoadPlainT<false> ldl{tmp};
     StorePruned stl{out, (int)n, keep};
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
+}
+
+bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int count) {
+    if (ef.npass() != 2 || ea.npass() != 2) return false;
+    const int64_t B = ef.desc().n, A = ea.desc().n;
+    if (A >= B || (A & 1) || ea.desc().pass[1].L != ef.desc().pass[0].L) return false;
+    return fftk::fft_tile2_decim_applies(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()), count);
+}
+
+void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float2* out, float2* tmp_a,
+                          int count, const float* wr, float scale, float2* dc, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t B = ef.desc().n, A = ea.desc().n;
+    fftk::LoadPlainT<false> ld{tmp_f};
+    WinAudioDecim win{wr, dc, scale, (int)A, ef.desc().pass[0].L};
+    fftk::StorePlainT<false> st{tmp_a, 1.0f};
+    RC_REQUIRE(fftk::launch_fft_tile2_decim(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()),
+                                            count, ld, win, st, s),
+               RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
+    fftk::LoadPlainT<false> ldl{tmp_a};
+    fftk::StorePlainT<true> stl{out, 1.0f};
+    fftk::launch_fft_pass<kRowsOnly>(ea.pass_dev(1, ea.tmp_stride(), A), count, ldl, stl, s);
 }
 
 void fused_stereo_unpack_ifft(const FftEngine& e, const float2* U, int64_t B, float2* out, float2* tmp, int count,
