@@ -793,9 +793,11 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
         if (chunk <= 0) {
             // Measured on MI355X (profiles/r01_c_chunk_sweep.txt): bigger chunks keep winning up to 512;
             // the kernels are tile-latency bound below ~64 channels per launch.
+            // Narrow channels (cfg5: B = 12 500) take proportionally more per launch, up to 2048 (+6 %).
             const char* e = std::getenv("RCFM_CHUNK");
-            chunk = e ? std::atoi(e) : 512;
-            if (chunk <= 0) chunk = 512;
+            const int dflt = (int)std::min<int64_t>(2048, std::max<int64_t>(512, (int64_t)512 * 240000 / B));
+            chunk = e ? std::atoi(e) : dflt;
+            if (chunk <= 0) chunk = dflt;
         }
         d->chunk = std::min(chunk, C);
         d->geom.build(B, A, 0.54 /* hamm */, false);

@@ -11,10 +11,23 @@
 
 // Each block handles tiles; a tile = L rows, each row a SEG-byte segment at row stride `pitch` elements (float2).
 // Lanes run along the segment (SEG/8 float2 per row), then rows.
-template <int SEGE>  // segment length in float2 elements (8 B each)
+// XCD: workgroups go to the 8 XCDs round-robin; with XCD = true each XCD walks a contiguous eighth of the
+// tile list, so neighbouring tiles (which share 128-byte lines when SEG < 128 B) meet in one L2.
+template <int SEGE, bool XCD = false>  // segment length in float2 elements (8 B each)
 __global__ __launch_bounds__(256) void k_tile_copy(const float2* __restrict__ in, float2* __restrict__ out,
                                                    long pitch, int L, long ntiles_per_row, long total_tiles) {
-    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    const long per_xcd = (total_tiles + 7) / 8, lanes = gridDim.x / 8;
+    for (long it = 0;; ++it) {
+        long t;
+        if (XCD) {
+            const long j = (long)(blockIdx.x >> 3) + lanes * it;
+            if (j >= per_xcd) break;
+            t = (long)(blockIdx.x & 7) * per_xcd + j;
+            if (t >= total_tiles) break;
+        } else {
+            t = blockIdx.x + it * (long)gridDim.x;
+            if (t >= total_tiles) break;
+        }
         // tile t covers columns [t % ntiles_per_row * SEGE, +SEGE) of block-row (t / ntiles_per_row)
         const long col0 = (t % ntiles_per_row) * SEGE;
         const long slab = (t / ntiles_per_row) * (long)L * pitch;
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256) void k_copy4(const float4* __restrict__ in, fl
     }
 }
 
-template <int SEGE>
+template <int SEGE, bool XCD = false>
 double run_tile(const float2* in, float2* out, long n_elems, long pitch, int L, int reps) {
     const long ntiles_per_row = pitch / SEGE;
     const long slabs = n_elems / ((long)L * pitch);
@@ -44,10 +57,10 @@ double run_tile(const float2* in, float2* out, long n_elems, long pitch, int L, 
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int grid = 256 * 8;
-    hipLaunchKernelGGL(k_tile_copy<SEGE>, dim3(grid), dim3(256), 0, 0, in, out, pitch, L, ntiles_per_row, total);
+    hipLaunchKernelGGL((k_tile_copy<SEGE, XCD>), dim3(grid), dim3(256), 0, 0, in, out, pitch, L, ntiles_per_row, total);
     CK(hipEventRecord(a));
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(k_tile_copy<SEGE>, dim3(grid), dim3(256), 0, 0, in, out, pitch, L, ntiles_per_row, total);
+        hipLaunchKernelGGL((k_tile_copy<SEGE, XCD>), dim3(grid), dim3(256), 0, 0, in, out, pitch, L, ntiles_per_row, total);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return 2.0 * 8.0 * (double)(slabs * (long)L * pitch) * reps / (ms * 1e-3) / 1e9;
@@ -73,7 +86,9 @@ int main() {
         const int L = (int)(n / pitch >= 500 ? 500 : n / pitch);
         printf("tile seg 32B  L=%d pitch=%ld : %8.1f GB/s\n", L, pitch, run_tile<4>(in, out, n, pitch, L, reps));
         printf("tile seg 64B  L=%d pitch=%ld : %8.1f GB/s\n", L, pitch, run_tile<8>(in, out, n, pitch, L, reps));
+        printf("tile seg 64B  L=%d pitch=%ld XCD-aware order : %8.1f GB/s\n", L, pitch, (run_tile<8, true>(in, out, n, pitch, L, reps)));
         printf("tile seg 128B L=%d pitch=%ld : %8.1f GB/s\n", L, pitch, run_tile<16>(in, out, n, pitch, L, reps));
+        printf("tile seg 128B L=%d pitch=%ld XCD-aware order : %8.1f GB/s\n", L, pitch, (run_tile<16, true>(in, out, n, pitch, L, reps)));
         printf("tile seg 256B L=%d pitch=%ld : %8.1f GB/s\n", L, pitch, run_tile<32>(in, out, n, pitch, L, reps));
     }
     return 0;
