@@ -280,7 +280,11 @@ struct rcfm_tuner_s {
         return *it->second;
     }
 
-    void run(int first, int count, float2* out, hipStream_t s) {
+    // Can run() leave angle(x) / pi instead of x for this channel's band?  (engine path only)
+    bool phase_capable(int first) { return first >= 0 && first < nch && band(bw[first]).engine != nullptr; }
+
+    // theta != nullptr (phase_capable bands only): angle(x) / pi goes to theta [count][B] float32, out is unused.
+    void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr) {
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
         RC_REQUIRE(loaded, RCFM_ERR_STATE, "rcfm_tuner_run called before rcfm_tuner_load");
         if (count == 0) return;
@@ -295,9 +299,10 @@ struct rcfm_tuner_s {
             TunerGather tg{spectrum(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode,
                            halo ? base_dev.as<int32_t>() + first : nullptr, halo};
             StageTimer tm(ST_TUNER_IFFT, s);
-            fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s);
+            fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s, theta);
             return;
         }
+        RC_REQUIRE(theta == nullptr, RCFM_ERR_STATE, "phase output needs the FFT engine");
         size_t need = 0;
         FftPlan& inv = bd.inverse.get(FftKind::C2C_INVERSE, (size_t)B, count, true, need);
         work.reserve(need);
@@ -419,7 +424,10 @@ struct rcfm_demod_s {
         }
     }
 
-    void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s) {
+    // Does run_chunk take the samples' phases (theta = angle(x) / pi, float32 [cnt][B]) instead of iq?
+    bool phase_capable() const { return eng_B != nullptr && (kind != RCFM_WBFM || B % 4 == 0); }
+
+    void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s, const float* theta = nullptr) {
         size_t need = 0;
         if (kind == RCFM_WBFM) {
             FftPlan* pf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -438,7 +446,9 @@ struct rcfm_demod_s {
             // wbfm.py:77-80  FM(B->B) and the pilot band-pass
             {
                 StageTimer tm(ST_PILOT, s);
-                if (B % 4 == 0)
+                if (theta != nullptr)
+                    launch_pilot_stage_h40_phase(theta, m, p, B, cnt, pilot_g_h, side_tap, s);
+                else if (B % 4 == 0)
                     launch_pilot_stage_h40(iq, m, p, B, cnt, pilot_g_h, side_tap, s);
                 else
                     launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
@@ -569,7 +579,8 @@ struct rcfm_demod_s {
         // fm.py:60-66  discriminator, then Decimate(B -> A)
         {
             StageTimer tm(ST_DISC, s);
-            launch_discriminator(iq, d, B, cnt, s);
+            if (theta != nullptr) launch_discriminator_phase(theta, d, B, cnt, s);
+            else launch_discriminator(iq, d, B, cnt, s);
         }
         if (eng_B) {
             float2* Dfull = buf_Z.as<float2>();
@@ -889,6 +900,19 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
         for (int off = 0; off < count; off += d->chunk) {
             const int cnt = std::min(d->chunk, count - off);
             RC_REQUIRE(t->bw[first + off] == d->B, RCFM_ERR_SIZE, "input_sig size and input_size mismatch");
+            // Every demodulator starts with the FM discriminator, which only needs the samples' phases:
+            // the tuner's last pass leaves angle(x) / pi (float32) instead of x (complex64) -- half the
+            // bytes written here and read back by the first demod kernel.  RCFM_PHASE_LINK=0: complex hand-over.
+            static const bool no_phase = [] {
+                const char* e = std::getenv("RCFM_PHASE_LINK");
+                return e && e[0] == '0';
+            }();
+            if (!no_phase && d->phase_capable() && t->phase_capable(first + off)) {
+                float* theta = d->buf_iq.as<float>();
+                t->run(first + off, cnt, nullptr, as_stream(stream), theta);
+                d->run_chunk(first + off, cnt, nullptr, outp + (size_t)off * d->A * d->ch, as_stream(stream), theta);
+                continue;
+            }
             t->run(first + off, cnt, d->buf_iq.as<float2>(), as_stream(stream));
             d->run_chunk(first + off, cnt, d->buf_iq.as<float2>(), outp + (size_t)off * d->A * d->ch,
                          as_stream(stream));

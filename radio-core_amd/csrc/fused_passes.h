@@ -21,8 +21,10 @@ struct TunerGather {
     const int32_t* base32 = nullptr;
     int64_t halo = 0;
 };
+// theta != nullptr: instead of out, angle(ifft) / pi goes to theta [count][B] float32 -- all an FM
+// discriminator needs (fm.py:60-65), and half the bytes.
 void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
-                      hipStream_t s);
+                      hipStream_t s, float* theta = nullptr);
 
 // Forward FFT of real signals x [count][n] -> full complex spectrum U [count][n].
 // keep >= 0: only bins |k| <= keep are written (the rest of U is left untouched).

@@ -1,4 +1,5 @@
 #include "fused_passes.h"
+#include "device_math.h"
 
 #include "fft_kernel.h"
 #include "kernels.h"
@@ -434,8 +435,17 @@ void middle_passes(const FftEngine& e, int from, int to, float2* tmp, int count,
 
 }  // namespace
 
+// Last pass of the tuner's inverse FFT when only the phase is wanted (the FM discriminator, fm.py:60-65):
+// angle(x) / pi as float32, half the bytes of x.  v arrives with re/im exchanged (swap identity).
+struct StorePhase {
+    float* theta;
+    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
+        (theta + base)[off] = atan2_over_pi(v.x, v.y);
+    }
+};
+
 void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
-                      hipStream_t s) {
+                      hipStream_t s, float* theta) {
     if (count <= 0) return;
     const int64_t B = e.desc().n;
     const int np = e.npass();
@@ -479,6 +489,10 @@ void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, flo
     }
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
+    if (theta != nullptr) {
+        fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), B), count, ldl, StorePhase{theta}, s);
+        return;
+    }
     fftk::StorePlainT<true> stl{out, (float)(1.0 / (double)g.N)};   // ifft (1/B) * (B/N)
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), B), count, ldl, stl, s);
 }

@@ -60,6 +60,11 @@ void launch_pilot_stage(const float2* iq, const float* x, float* m_out, float* p
 // Needs n % 4 == 0 (16-byte stores) and n > 123.
 void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
                             const float* g_host, float side_tap, hipStream_t stream);
+// The same chain from the samples' phases theta = angle(x) / pi (what the pipeline's tuner stage leaves,
+// fused_tuner_ifft): d[i] = the phase step wrapped into [-1, 1], exactly diff(unwrap(angle(x))) / pi.
+void launch_pilot_stage_h40_phase(const float* theta, float* m_out, float* p_out, int64_t n, int batch,
+                                  const float* g_host, float side_tap, hipStream_t stream);
+void launch_discriminator_phase(const float* theta, float* d, int64_t n, int batch, hipStream_t stream);
 
 // wbfm.py:83,86-87: s2 = Im(z^2)/|z^2|; lmr = s2 m 1.0175; u = (m + lmr) + j (m - lmr).
 void launch_stereo_mix(const float2* z, const float* m, float2* u, size_t count, hipStream_t stream);

@@ -7,6 +7,7 @@
 // scipy calls) is derived in DESIGN.md and pinned by tests/test_oracle_scipy.py.
 
 #include "kernels.h"
+#include "device_math.h"
 
 namespace rcfm {
 
@@ -278,32 +279,15 @@ __device__ __forceinline__ void pk_fma_s_rev(v2f& acc, v2f taps, v2f w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(taps), "v"(w));
 }
 
-// atan2(y, x) / pi for the discriminator: odd minimax polynomial of min/max (degree 17, 1e-7 rad),
-// octant folding by selects; (0, 0) -> 0 like numpy.angle.
-__device__ __forceinline__ float atan2_over_pi(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
-    const float a = mn * __builtin_amdgcn_rcpf(mx);
-    const float t = a * a;
-    float p = 0.002479950897395611f;
-    p = fmaf(p, t, -0.014499950222671032f);
-    p = fmaf(p, t, 0.039953526109457016f);
-    p = fmaf(p, t, -0.0725083202123642f);
-    p = fmaf(p, t, 0.10507379472255707f);
-    p = fmaf(p, t, -0.14163753390312195f);
-    p = fmaf(p, t, 0.19986307621002197f);
-    p = fmaf(p, t, -0.3333262503147125f);
-    p = fmaf(p, t, 0.9999998807907104f);
-    float r = (p * a) * kInvPi;          // [0, 1/4]
-    r = (ay > ax) ? 0.5f - r : r;        // [0, 1/2]
-    r = (x < 0.f) ? 1.f - r : r;         // [0, 1]
-    return copysignf(r, y);
-}
 __device__ __forceinline__ float phase_step_fast(float2 a, float2 b) {
     return atan2_over_pi(a.y * b.x - a.x * b.y, a.x * b.x + a.y * b.y);
 }
+// the same step when the tuner already left angle(x) / pi (fused_tuner_ifft's phase output)
+__device__ __forceinline__ float phase_step_fast(float th, float th_prev) { return phase_step_wrapped(th, th_prev); }
 
-__global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const float2* __restrict__ iq,
+// IN = float2: complex samples; IN = float: their phases in units of pi.
+template <class IN>
+__global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restrict__ iq,
                                                               float* __restrict__ m_out,
                                                               float* __restrict__ p_out, int64_t n,
                                                               PilotTaps taps, float side_tap,
@@ -322,16 +306,16 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const float2* __re
     const int n32 = (int)n;
     const int t0 = (int)(vid - (unsigned)c * tiles_x) * T;
     const int q0 = t0 - H;
-    const float2* xc = iq + (int64_t)c * n;
+    const IN* xc = iq + (int64_t)c * n;
     // workgroup-uniform: the tile and its halos lie strictly inside the channel (no wrap, no reflection)
     const bool interior = (q0 - 2 >= 0) && (q0 + T + 2 * H + 1 <= n32 - 1);
     // discriminator: both samples of every pair are fetched unconditionally (clamped index) and
     // up front, 18 loads in flight per thread; a load inside the loop's `if` would serialise
     // one HBM round trip per iteration
     constexpr int ND = (T + 2 * H + 2 + kThreads - 1) / kThreads;
-    float2 xa[ND], xb[ND];
+    IN xa[ND], xb[ND];
     if (interior) {
-        const float2* x0 = xc + (q0 - 1 + tid);
+        const IN* x0 = xc + (q0 - 1 + tid);
 #pragma unroll
         for (int it = 0; it < ND; ++it) {
             // the last sweep is ragged: clamp instead of branching (the value is not stored)
@@ -767,14 +751,30 @@ void launch_stereo_unpack(const float2* U, int64_t B, float2* V, int64_t A, int 
     RC_LAUNCH_CHECK();
 }
 
+__global__ __launch_bounds__(kThreads) void k_discriminator_phase(const float* __restrict__ theta,
+                                                                  float* __restrict__ d, int64_t n) {
+    const int c = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float* tc = theta + (int64_t)c * n;
+    d[(int64_t)c * n + i] = (i == 0) ? 0.f : phase_step_wrapped(tc[i], tc[i - 1]);
+}
+
+void launch_discriminator_phase(const float* theta, float* d, int64_t n, int batch, hipStream_t stream) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(k_discriminator_phase, grid2(n, kThreads, batch), dim3(kThreads), 0, stream, theta, d, n);
+    RC_LAUNCH_CHECK();
+}
+
 void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipStream_t stream) {
     if (batch <= 0) return;
     hipLaunchKernelGGL(k_discriminator, grid2(n, kThreads, batch), dim3(kThreads), 0, stream, iq, d, n);
     RC_LAUNCH_CHECK();
 }
 
-void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
-                            const float* g_host, float side_tap, hipStream_t stream) {
+template <class IN>
+static void launch_pilot_stage_h40_t(const IN* iq, float* m_out, float* p_out, int64_t n, int batch,
+                                     const float* g_host, float side_tap, hipStream_t stream) {
     if (batch <= 0) return;
     PilotTaps taps;   // h[t] = g[|t - 40|], t = 0..80, h[81] = 0
     for (int j = 0; j <= 40; ++j) {
@@ -784,9 +784,19 @@ void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_
     }
     const unsigned tiles_x = (unsigned)((n + kPilotFastTile - 1) / kPilotFastTile);
     const unsigned blocks = (tiles_x * (unsigned)batch + 7u) / 8u * 8u;
-    hipLaunchKernelGGL(k_pilot_stage_h40, dim3(blocks), dim3(kThreads), 0, stream, iq, m_out, p_out, n, taps,
+    hipLaunchKernelGGL(k_pilot_stage_h40<IN>, dim3(blocks), dim3(kThreads), 0, stream, iq, m_out, p_out, n, taps,
                        side_tap, tiles_x, (unsigned)batch);
     RC_LAUNCH_CHECK();
+}
+
+void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
+                            const float* g_host, float side_tap, hipStream_t stream) {
+    launch_pilot_stage_h40_t(iq, m_out, p_out, n, batch, g_host, side_tap, stream);
+}
+
+void launch_pilot_stage_h40_phase(const float* theta, float* m_out, float* p_out, int64_t n, int batch,
+                                  const float* g_host, float side_tap, hipStream_t stream) {
+    launch_pilot_stage_h40_t(theta, m_out, p_out, n, batch, g_host, side_tap, stream);
 }
 
 void launch_pilot_stage(const float2* iq, const float* x, float* m_out, float* p_out, int64_t n,
