@@ -577,18 +577,21 @@ struct rcfm_demod_s {
         }
         float* d = buf_m.as<float>();
         // fm.py:60-66  discriminator, then Decimate(B -> A)
-        {
+        if (theta == nullptr) {
             StageTimer tm(ST_DISC, s);
-            if (theta != nullptr) launch_discriminator_phase(theta, d, B, cnt, s);
-            else launch_discriminator(iq, d, B, cnt, s);
+            launch_discriminator(iq, d, B, cnt, s);
         }
         if (eng_B) {
             float2* Dfull = buf_Z.as<float2>();
             float2* Yfull = buf_V.as<float2>();
             {
                 StageTimer tm(ST_FFT_REAL_B, s);
-                // two channels per complex FFT; only |k| <= A/2 is kept (and read back by the unpacking)
-                fused_real_pair_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
+                // two channels per complex FFT; only |k| <= A/2 is kept (and read back by the unpacking).
+                // From the tuner's phases the discriminator is the load of the first pass.
+                if (theta != nullptr)
+                    fused_real_pair_fft(*eng_B, theta, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s, true);
+                else
+                    fused_real_pair_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
             }
             {
                 StageTimer tm(ST_AUDIO_SPECTRUM, s);

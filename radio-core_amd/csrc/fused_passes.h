@@ -43,8 +43,10 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
 // keep >= 0: only bins |k| <= keep of U2 are written; kKeepLowerHalf: only bins 0 .. n/2 (all the packed
 // Hilbert chain below reads).
 constexpr int kKeepLowerHalf = -2;
+// from_phase: x holds angle / pi of complex samples and the real signals are its wrapped steps -- the FM
+// discriminator (fm.py:60-65) computed on the load, d[0] = 0.
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2* tmp, int count, int keep,
-                         hipStream_t s);
+                         hipStream_t s, bool from_phase = false);
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const float* m, float2* u, float2* tmp,
                                  int count, hipStream_t s);
 

@@ -147,6 +147,31 @@ struct LoadRealPair {
     __device__ __forceinline__ float2 post(const LineId&, int, float2 v) const { return v; }
 };
 
+// The same pair with the FM discriminator (fm.py:60-65) on the load: theta = angle(x) / pi of the two
+// channels; the real signals are the wrapped phase steps d[t] = wrap(theta[t] - theta[t-1]), d[0] = 0.
+struct LoadPhaseStepPair {
+    static constexpr int kFetches = 2;
+    const float* theta;
+    int n, count;
+    int line_stride;
+    __device__ __forceinline__ float2 at(const LineId& id, int t) const {
+        const int c0 = 2 * id.batch, c1 = (c0 + 1 < count) ? c0 + 1 : c0;
+        return make_float2(theta[(int64_t)c0 * n + t], theta[(int64_t)c1 * n + t]);
+    }
+    __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t, unsigned) const {
+        return at(id, l * line_stride + (int)id.i);
+    }
+    __device__ __forceinline__ float2 fetch2(const LineId& id, int l, int64_t, unsigned) const {
+        const int t = l * line_stride + (int)id.i;
+        return at(id, t > 0 ? t - 1 : 0);
+    }
+    __device__ __forceinline__ float2 post(const LineId& id, int l, float2 a, float2 b) const {
+        const int t = l * line_stride + (int)id.i;
+        if (t == 0) return make_float2(0.f, 0.f);
+        return make_float2(phase_step_wrapped(a.x, b.x), phase_step_wrapped(a.y, b.y));
+    }
+};
+
 // Hilbert mask applied to one member of such a pair: with U = FFT(x0 + j x1),
 // X0[k] = (U[k] + conj U[-k]) / 2, X1[k] = (U[k] - conj U[-k]) / 2j; Z = h X, bins above n/2 are 0.
 // HZ: the pass is the first of a two-pass plan of even length (point k = l * stride + i, n = L *
@@ -526,14 +551,19 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
 }
 
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
-                         hipStream_t s) {
+                         hipStream_t s, bool from_phase) {
     if (count <= 0) return;
     const int64_t n = e.desc().n;
     const int np = e.npass();
     const int pairs = (count + 1) / 2;
-    LoadRealPair ld{x, (int)n, count};
     fftk::StorePlainT<false> st0{tmp, 1.0f};
-    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
+    if (from_phase) {
+        LoadPhaseStepPair ld{x, (int)n, count, (int)e.desc().pass[0].in_l};
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
+    } else {
+        LoadRealPair ld{x, (int)n, count};
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
+    }
     middle_passes(e, 1, np - 2, tmp, pairs, s);
     fftk::LoadPlainT<false> ldl{tmp};
     if (keep >= 0 || keep == kKeepLowerHalf) {
