@@ -496,10 +496,11 @@ struct rcfm_demod_s {
                     return e && e[0] == '0';
                 }();
                 if (paired && eng_Ad && !no_decim && fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, cnt)) {
-                    // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
-                    StageTimer tm(ST_FFT_B, s);
-                    fused_fft_decim_ifft(*eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
-                                         buf_dc.as<float2>(), s);
+                    {   // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
+                        StageTimer tm(ST_FFT_B, s);
+                        fused_fft_decim_ifft(*eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
+                                             buf_dc.as<float2>(), s);
+                    }
                     float* st = state.as<float>() + (size_t)first * ch * 50;
                     run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true);
                     return;
