@@ -293,7 +293,11 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
                                                               PilotTaps taps, float side_tap,
                                                               unsigned tiles_x, unsigned batch) {
     constexpr int H = 40, T = kPilotFastTile, PER = kPilotPer;
-    __shared__ __attribute__((aligned(16))) float m_s[T + 2 * H];        // m[q0 + s]
+    // m[q0 + e] lives at mpos(e): 8 values, 2 pad dwords.  The FIR reads each thread's window (thread tid
+    // starts at e = 8 tid) with ds_read_b64: at a lane stride of 8 dwords those were 8-way bank conflicts
+    // (SQ_LDS_BANK_CONFLICT = 69 % of the LDS cycles); at 10 dwords the 64 lanes x 2 dwords spread evenly.
+    auto mpos = [](int e) -> int { return (e >> 3) * 10 + (e & 7); };
+    __shared__ __attribute__((aligned(16))) float m_s[((T + 2 * H + 7) / 8) * 10];
     __shared__ __attribute__((aligned(16))) float d_s[T + 2 * H + 2];    // d[q0 - 1 + s] (circular)
     // XCD-aware order (workgroups go to the 8 XCDs round-robin, each XCD has its own L2): XCD k walks
     // a contiguous eighth of the (channel, tile) list, so the halo lines two neighbouring tiles share
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
         for (int it = 0; it < (T + 2 * H + kThreads - 1) / kThreads; ++it) {
             const int s = tid + kThreads * it;
             if (s < T + 2 * H) {
-                m_s[s] = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
+                m_s[mpos(s)] = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
             }
         }
     } else {
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
                 v = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
                 if (q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
             }
-            m_s[s] = v;
+            m_s[mpos(s)] = v;
         }
     }
     __syncthreads();
@@ -373,8 +377,9 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
     const int o = tid * PER;
     if (interior) {   // m leaves as 16-byte stores like p
         float4* dst = reinterpret_cast<float4*>(m_out + (int64_t)c * n + t0 + o);
-        dst[0] = *reinterpret_cast<const float4*>(&m_s[H + o]);
-        dst[1] = *reinterpret_cast<const float4*>(&m_s[H + o + 4]);
+        const v2f* src = reinterpret_cast<const v2f*>(&m_s[mpos(H + o)]);   // H + o is a multiple of 8
+        dst[0] = make_float4(src[0].x, src[0].y, src[1].x, src[1].y);
+        dst[1] = make_float4(src[2].x, src[2].y, src[3].x, src[3].y);
     }
     if (t0 - H >= 0 && t0 + T - 1 + H <= last) {   // workgroup-uniform: no reflection anywhere in the tile
         // out[r] = sum_t h[t] w[r + t], t = 0..80, w = m_s + o, two taps per packed FMA (lane 0: the
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
         // and are read from LDS as they are needed (16 live registers instead of the 88 of the whole
         // window: twice the waves per SIMD, which is what hides the HBM latency of the next tile).
         auto wpair = [&](int pi) -> v2f {
-            v2f q = *reinterpret_cast<const v2f*>(&m_s[o + 2 * pi]);
+            v2f q = *reinterpret_cast<const v2f*>(&m_s[mpos(o + 2 * pi)]);
             asm volatile("" : "+v"(q));   // keep the 8-byte read (and its place in the sequence)
             return q;
         };
@@ -425,16 +430,16 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
         const v2f pr = taps.pair[(H + j) >> 1];
         return ((H + j) & 1) ? pr.y : pr.x;
     };
-    const float m_first = (q0 <= 0) ? m_s[0 - q0] : 0.f;
-    const float m_last = (last - q0 < T + 2 * H) ? m_s[last - q0] : 0.f;
+    const float m_first = (q0 <= 0) ? m_s[mpos(0 - q0)] : 0.f;
+    const float m_last = (last - q0 < T + 2 * H) ? m_s[mpos(last - q0)] : 0.f;
     for (int r = 0; r < PER; ++r) {
         const int i = t0 + o + r;
         if (i >= n32) break;
-        float acc = tap(0) * m_s[o + r + H];
+        float acc = tap(0) * m_s[mpos(o + r + H)];
         for (int j = 1; j <= H; ++j) {
             const int ql = i - j, qr = i + j;
-            const float el = (ql < 0) ? 2.f * m_first - m_s[-ql - q0] : m_s[ql - q0];
-            const float er = (qr > last) ? 2.f * m_last - m_s[2 * last - qr - q0] : m_s[qr - q0];
+            const float el = (ql < 0) ? 2.f * m_first - m_s[mpos(-ql - q0)] : m_s[mpos(ql - q0)];
+            const float er = (qr > last) ? 2.f * m_last - m_s[mpos(2 * last - qr - q0)] : m_s[mpos(qr - q0)];
             acc = fmaf(tap(j), el + er, acc);
         }
         p_out[(int64_t)c * n + i] = acc;
