@@ -562,7 +562,11 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
     constexpr int HP = (HIST + 3) / 4 * 4;                          // history rounded to whole 16-byte loads
     constexpr int NW = (PER + HP) / 4;                              // float4 window reads per thread
     constexpr int NV = (T + HP) / 4;                                // float4 loads per workgroup
-    __shared__ __attribute__((aligned(16))) float x_s[T + HP];      // z[t0 - HP + s]
+    // z[t0 - HP + e] lives at xpos(e): 8 values, 4 pad dwords -- the window reads (thread tid starts at
+    // e = 8 tid) are ds_read_b128 at a lane stride of 12 dwords instead of 8: no bank conflicts beyond the
+    // 4 cycles 64 lanes x 16 bytes need anyway.
+    auto xpos = [](int e) -> int { return (e >> 3) * 12 + (e & 7); };
+    __shared__ __attribute__((aligned(16))) float x_s[((T + HP + 7) / 8) * 12];
     __shared__ float red[kThreads / 64];
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         const int q = tid + kThreads * it;
         const int64_t e = t0 - HP + 4 * (int64_t)q;
         if (q < NV)
-            *reinterpret_cast<float4*>(&x_s[4 * q]) = (e >= 0 && e < total) ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&x_s[xpos(4 * q)]) = (e >= 0 && e < total) ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float mean = 0.f;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
     float w[NW * 4];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        float4 q4 = *reinterpret_cast<const float4*>(&x_s[o + 4 * j]);
+        float4 q4 = *reinterpret_cast<const float4*>(&x_s[xpos(o + 4 * j)]);
         asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w));   // keep the 16-byte reads
         w[4 * j] = q4.x;
         w[4 * j + 1] = q4.y;
