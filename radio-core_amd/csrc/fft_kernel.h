@@ -70,6 +70,21 @@ __device__ __forceinline__ float2 cadd_pi(float2 t, float2 u) {
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global loads and
+// stores share that counter on gfx9): in the multi-transform tile kernels that would wait, at every
+// stage boundary, for the point-wise stage's prefetched inputs and for the stores of the transform just
+// finished.  LDS hand-offs only need lgkmcnt(0) + s_barrier.
+#ifndef RCFM_LDS_BARRIER
+#define RCFM_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if RCFM_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // ---- small forward DFTs, y[q'] = sum_q x[q] exp(-2 pi i q q' / R), in place --------
 
 __device__ __forceinline__ void dft2(float2& a, float2& b) {
@@ -785,16 +800,16 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
         float2 x = load.post(id, l, v[it]);
         if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
     }
-    __syncthreads();
+    lds_barrier();
     stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
-    __syncthreads();
+    lds_barrier();
     if constexpr (S >= 3) {
         stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (S >= 4) {
         stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- last stage of the first transform: results leave their digit-reversed slots, pass the
@@ -810,7 +825,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
             dft_p<RL>(&xr[it * RL]);
         }
     }
-    __syncthreads();   // every slot has been read
+    lds_barrier();   // every slot has been read
 #pragma unroll
     for (int it = 0; it < nitL; ++it) {
         const int g = rg + RG * it;
@@ -824,18 +839,18 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- second transform: a strided pass of plan 2 whose input already sits in LDS ----------
     stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
-    __syncthreads();
+    lds_barrier();
     if constexpr (S >= 3) {
         stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (S >= 4) {
         stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
     const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
     const float2 D = big_twiddle(d2, f * (unsigned)(L / RL));
@@ -953,16 +968,16 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
         const float2 x = load.post(id, l, v[it]);
         if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
     }
-    __syncthreads();
+    lds_barrier();
     stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
-    __syncthreads();
+    lds_barrier();
     if constexpr (S >= 3) {
         stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (S >= 4) {
         stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- point-wise inputs of member 0 (and of the split), then the last stage ----------------
@@ -994,7 +1009,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
         }
         __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisted LDS reads of the next rows would spill
     }
-    __syncthreads();   // every slot has been read
+    lds_barrier();   // every slot has been read
 #pragma unroll
     for (int it = 0; it < nitL; ++it) {
         const int g = rg + RG * it;
@@ -1004,7 +1019,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
             for (int q = 0; q < RL; ++q) tile[lds_slot<true>(kb + (L / RL) * q, w)] = u0[it * RL + q];
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- second transform (a strided pass of plan 2 whose input already sits in LDS), per member
     const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
@@ -1012,14 +1027,14 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
     const bool lane_ok = w < wvalid;
     auto second_transform = [&](int64_t out_base) {
         stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
         if constexpr (S >= 3) {
             stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
-            __syncthreads();
+            lds_barrier();
         }
         if constexpr (S >= 4) {
             stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
-            __syncthreads();
+            lds_barrier();
         }
 #pragma unroll
         for (int it = 0; it < nitL; ++it) {
@@ -1052,7 +1067,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
 
     second_transform(out_base0);
     if (!has1) return;   // workgroup-uniform
-    __syncthreads();     // member 0's last stage has read every slot
+    lds_barrier();     // member 0's last stage has read every slot
 #pragma unroll
     for (int it = 0; it < nitL; ++it) {
         const int g = rg + RG * it;
@@ -1065,7 +1080,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     second_transform(out_base1);
 }
 
@@ -1153,16 +1168,16 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
         const float2 x = load.post(id, l, v[it]);
         if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
     }
-    __syncthreads();
+    lds_barrier();
     stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
-    __syncthreads();
+    lds_barrier();
     if constexpr (S >= 3) {
         stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (S >= 4) {
         stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- last stage of transform 1; the surviving rows land in natural order -------------------
@@ -1176,7 +1191,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
             dft_p<RL>(&xr[it * RL]);
         }
     }
-    __syncthreads();   // every slot has been read
+    lds_barrier();   // every slot has been read
 #pragma unroll
     for (int it = 0; it < nitL; ++it) {
         const int g = rg + RG * it;
@@ -1197,7 +1212,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
         }
     }
     for (int e = tid; e < L2; e += T) tw[e] = d2.stage_tw[e];   // (every read of transform 1's table is done)
-    __syncthreads();
+    lds_barrier();
 
     // ---- weights, Nyquist merge, swap for the inverse transform ----------------------------------
 #pragma unroll
@@ -1218,11 +1233,11 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
             tile[lds_slot<true>(l, wl)] = make_float2(x.y, x.x);
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- transform 2: a strided pass of the short plan whose input sits in LDS ---------------------
     stage_lds<L2, Q0, L2, true, RG>(tile, tw, w, rg);
-    __syncthreads();
+    lds_barrier();
     constexpr int rows2 = L2 / Q1;
     static_assert(rows2 <= RG, "short transform: one sweep");
     id.i = i0 + w;
