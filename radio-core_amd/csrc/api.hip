@@ -369,14 +369,16 @@ struct rcfm_demod_s {
                     const int64_t swapped[2] = {pd.pass[1].L, pd.pass[0].L};
                     eng_Bi = std::make_unique<FftEngine>(B, swapped, 2);
                     buf_Ti.reset(c * eng_Bi->tmp_stride() * sizeof(float2));
-                    // decimation between FFT_B's last pass and IFFT_A's first (fused_passes.h)
-                    const int64_t n1 = pd.pass[0].L;
-                    const int64_t fa[2] = {A / n1, n1};
-                    FftPlanDesc pa;
-                    if (A < B && A % (2 * n1) == 0 && fft_plan_describe(A, &pa, 0, fa, 2)) {
-                        eng_Ad = std::make_unique<FftEngine>(A, fa, 2);
-                        buf_TA.reserve(c * eng_Ad->tmp_stride() * sizeof(float2));
-                    }
+                }
+            }
+            {   // decimation between FFT_B's last pass and IFFT_A's first (fused_passes.h)
+                const FftPlanDesc& pd = eng_B->desc();
+                const int64_t n1 = pd.pass[0].L;
+                const int64_t fa[2] = {A / n1, n1};
+                FftPlanDesc pa;
+                if (pd.npass == 2 && A < B && A % (2 * n1) == 0 && fft_plan_describe(A, &pa, 0, fa, 2)) {
+                    eng_Ad = std::make_unique<FftEngine>(A, fa, 2);
+                    buf_TA.reserve(c * eng_Ad->tmp_stride() * sizeof(float2));
                 }
             }
             if (kind != RCFM_WBFM) {
@@ -581,6 +583,30 @@ struct rcfm_demod_s {
         if (theta == nullptr) {
             StageTimer tm(ST_DISC, s);
             launch_discriminator(iq, d, B, cnt, s);
+        }
+        static const bool no_decim_pairs = [] {
+            const char* e = std::getenv("RCFM_DECIM_TILE");
+            return e && e[0] == '0';
+        }();
+        if (eng_B && eng_Ad && !no_decim_pairs && ((int64_t)A % 4 == 0 || kind == RCFM_FM) &&
+            fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, (cnt + 1) / 2)) {
+            // two channels per complex signal from the pair FFT through the decimation to the inverse FFT:
+            // 3 launches, no B-point spectrum in memory, half the inverse transforms
+            {
+                StageTimer tm(ST_FFT_REAL_B, s);
+                fused_real_pair_fft_first(*eng_B, theta != nullptr ? theta : d, buf_T.as<float2>(), cnt,
+                                          theta != nullptr, s);
+            }
+            float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
+            {
+                StageTimer tm(ST_IFFT_A, s);
+                fused_fft_decim_ifft_pairs(*eng_B, *eng_Ad, buf_T.as<float2>(), dst, buf_TA.as<float2>(), cnt,
+                                           geom.wr.as<float>(), geom.scale, buf_dc.as<float2>(), s);
+            }
+            if (kind == RCFM_FM) return;
+            float* st = state.as<float>() + (size_t)first * 50;
+            run_deemph(dst, audio, st, cnt, s, true);
+            return;
         }
         if (eng_B) {
             float2* Dfull = buf_Z.as<float2>();

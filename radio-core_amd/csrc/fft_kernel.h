@@ -1438,7 +1438,9 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
 
 // Spectral decimation between two transforms (k_fft_tile2_decim): (long last-pass length, short
 // first-pass length) pairs with an instantiation.
-#define RCFM_FFT_DECIM_PAIRS(X) X(500, 10, 10, 5, 1, 100, 10, 10)
+#define RCFM_FFT_DECIM_PAIRS(X)          \
+    X(500, 10, 10, 5, 1, 100, 10, 10)    \
+    X(125, 5, 5, 5, 1, 80, 10, 8)
 
 inline bool fft_tile2_decim_applies(const FftPassDev& d1, const FftPassDev& d2, int batch) {
     bool fast = false;

@@ -85,6 +85,15 @@ bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int 
 void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float2* out, float2* tmp_a,
                           int count, const float* wr, float scale, float2* dc, hipStream_t s);
 
+// The same decimation for PAIRS of real channels (FM / MFM, fm.py:66): tmp_f holds the first pass of the
+// pair FFT (fused_real_pair_fft_first: x real signals, or their phases with the discriminator on the load);
+// the packed pair is decimated like one complex signal and one inverse transform returns channel 2P in the
+// real part, 2P+1 in the imaginary part: y [count][A] float32; dc [count] receives (sum y_c / A, 0).
+void fused_real_pair_fft_first(const FftEngine& e, const float* x, float2* tmp, int count, bool from_phase,
+                               hipStream_t s);
+void fused_fft_decim_ifft_pairs(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float* y,
+                                float2* tmp_a, int count, const float* wr, float scale, float2* dc, hipStream_t s);
+
 // wbfm.py:86-87: audio decimation of both stereo legs.  U [count][B] = FFT_B of the packed signal (only
 // |k| <= A/2 is read); the unpacking into the packed Hermitian spectrum of l + j r, the Hamming weight and
 // the Nyquist rule of decimate.py:48 are the load of IFFT_A's first pass; out [count][A] = l + j r

@@ -407,6 +407,7 @@ struct WinAudioDecim {
     float2* dc;        // [count] or null: receives V[c][0] = (sum l, sum r) / A
     float scale;
     int A, n1;
+    int split_count;   // > 0: the signal is a PAIR of real channels (2P, 2P+1): dc[2P] = (Re, 0), dc[2P+1] = (Im, 0)
     __device__ __forceinline__ float weight(const LineId&, int l, int k0) const {
         const int kappa = l * n1 + k0;
         int kk = kappa <= A / 2 ? kappa : A - kappa;
@@ -414,7 +415,13 @@ struct WinAudioDecim {
         return wr[kk] * scale;
     }
     __device__ __forceinline__ void dc_bin(const LineId& id, float2 v) const {
-        if (dc != nullptr) dc[id.batch] = v;
+        if (dc == nullptr) return;
+        if (split_count > 0) {
+            dc[2 * id.batch] = make_float2(v.x, 0.f);
+            if (2 * id.batch + 1 < split_count) dc[2 * id.batch + 1] = make_float2(v.y, 0.f);
+        } else {
+            dc[id.batch] = v;
+        }
     }
 };
 
@@ -705,7 +712,7 @@ void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2
     if (count <= 0) return;
     const int64_t B = ef.desc().n, A = ea.desc().n;
     fftk::LoadPlainT<false> ld{tmp_f};
-    WinAudioDecim win{wr, dc, scale, (int)A, ef.desc().pass[0].L};
+    WinAudioDecim win{wr, dc, scale, (int)A, ef.desc().pass[0].L, 0};
     fftk::StorePlainT<false> st{tmp_a, 1.0f};
     RC_REQUIRE(fftk::launch_fft_tile2_decim(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()),
                                             count, ld, win, st, s),
@@ -713,6 +720,50 @@ void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2
     fftk::LoadPlainT<false> ldl{tmp_a};
     fftk::StorePlainT<true> stl{out, 1.0f};
     fftk::launch_fft_pass<kRowsOnly>(ea.pass_dev(1, ea.tmp_stride(), A), count, ldl, stl, s);
+}
+
+// Last pass of an inverse transform that carried two real signals: real part -> channel 2P, imaginary
+// part -> channel 2P+1 of y [count][n] (v arrives with re/im exchanged).
+struct StoreRealImagSplit {
+    float* y;
+    int n, count;
+    __device__ __forceinline__ void operator()(const LineId& id, int, int64_t base, unsigned off, float2 v) const {
+        const int64_t t = base + off - (int64_t)id.batch * n;          // sample index
+        const int c0 = 2 * id.batch;
+        y[(int64_t)c0 * n + t] = v.y;
+        if (c0 + 1 < count) y[(int64_t)(c0 + 1) * n + t] = v.x;
+    }
+};
+
+void fused_real_pair_fft_first(const FftEngine& e, const float* x, float2* tmp, int count, bool from_phase,
+                               hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int pairs = (count + 1) / 2;
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    if (from_phase) {
+        LoadPhaseStepPair ld{x, (int)n, count, (int)e.desc().pass[0].in_l};
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
+    } else {
+        LoadRealPair ld{x, (int)n, count};
+        fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
+    }
+}
+
+void fused_fft_decim_ifft_pairs(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float* y,
+                                float2* tmp_a, int count, const float* wr, float scale, float2* dc, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t B = ef.desc().n, A = ea.desc().n;
+    const int pairs = (count + 1) / 2;
+    fftk::LoadPlainT<false> ld{tmp_f};
+    WinAudioDecim win{wr, dc, scale, (int)A, ef.desc().pass[0].L, count};
+    fftk::StorePlainT<false> st{tmp_a, 1.0f};
+    RC_REQUIRE(fftk::launch_fft_tile2_decim(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()),
+                                            pairs, ld, win, st, s),
+               RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
+    fftk::LoadPlainT<false> ldl{tmp_a};
+    StoreRealImagSplit stl{y, (int)A, count};
+    fftk::launch_fft_pass<kRowsOnly>(ea.pass_dev(1, ea.tmp_stride(), A), pairs, ldl, stl, s);
 }
 
 void fused_stereo_unpack_ifft(const FftEngine& e, const float2* U, int64_t B, float2* out, float2* tmp, int count,
