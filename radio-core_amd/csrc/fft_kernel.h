@@ -6,8 +6,15 @@
 // float2, pitch 16.  With lanes running along the 16 lines every ds_read_b64 /
 // ds_write_b64 of a 16-lane group covers one 128-byte row: conflict-free by
 // construction (MI355X_MICROARCH.md, LDS table).  Passes whose lines are contiguous in
-// memory load with lanes along l instead; their rows are XOR-swizzled
-// (lane ^ (row & 15)) so that the transposing store is conflict-free as well.
+// memory load with lanes along l instead; their rows have a pitch of 17 points
+// (kRowsPitch) so that the transposing store is conflict-free as well.
+//
+// Kernels in this file:
+//   k_fft_pass          runtime-radix fallback for lengths without a specialisation
+//   k_fft_tile          one pass, compile-time length and radices (the workhorse)
+//   k_fft_tile2         last pass of one plan + point-wise stage + first pass of the swapped plan
+//   k_fft_tile2_pair    the same for a transform that carried two real signals (two second transforms)
+//   k_fft_tile2_decim   last pass of a long plan + spectral decimation + first pass of a short one
 #pragma once
 
 #include <hip/hip_runtime.h>
