@@ -6,7 +6,9 @@
 One step = one pass of the hot path over one 1-second wideband buffer that is
 already resident in HBM: Tuner.load (FFT of N = 240 000 000 complex64 samples)
 then, for this rank's share of the 1024 channels, Tuner.run + WBFM.run
-(240 kHz -> 48 kHz stereo), then (N > 1) the RCCL gather of the audio to rank 0.
+(240 kHz -> 48 kHz stereo), then (N > 1) the RCCL gather of the audio to rank 0
+(asynchronous on double-buffered blocks: it runs under the kernels of the next
+buffer; every gather completes inside the timed region).
 Channels shard across ranks; the wideband FFT cannot shard by channel and is
 replicated, so total work is fixed as ranks grow: "scaling": "strong".
 
