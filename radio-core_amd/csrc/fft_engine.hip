@@ -16,6 +16,22 @@ constexpr double kTwoPi = 6.28318530717958647692;
 
 // Largest-radix-first factorisation of an LDS transform length.
 bool choose_radices(int L, int* radix, int* nstages) {
+    // lengths with a specialised kernel: the radices that kernel was instantiated with
+    switch (L) {
+#define RCFM_CASE(LEN, A, B, C, D)                          \
+    case LEN: {                                             \
+        const int r[4] = {A, B, C, D};                      \
+        int ns = 0;                                         \
+        for (int i = 0; i < 4; ++i)                         \
+            if (r[i] > 1) radix[ns++] = r[i];               \
+        *nstages = ns;                                      \
+        return true;                                        \
+    }
+        RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+        RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
+#undef RCFM_CASE
+        default: break;
+    }
     static const int kRadix[] = {10, 8, 6, 5, 4, 3, 2};
     int rem = L, ns = 0;
     while (rem > 1) {

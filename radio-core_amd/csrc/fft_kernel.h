@@ -134,6 +134,52 @@ __device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2&
     x3 = cadd_pi(t2, u2);
 }
 
+// Composite radices (12, 15, 16, 20, 24, 25, 32, ...): a natural-order in-register DFT built from the
+// radix-2/3/4/5 kernels, R = Ra Rb: Rb transforms of length Ra over the strided sub-sequences, constant
+// twiddles W_R^(n2 k1) (folded at compile time), Ra transforms of length Rb (recursively).  Two LDS stages
+// of radix ~22 replace three of radix ~8 for the 480..640-point tiles: a third fewer LDS round trips and
+// one barrier phase less per transform.
+template <int R>
+__device__ __forceinline__ void dft_nat(float2* v) {
+    if constexpr (R == 2) {
+        dft2(v[0], v[1]);
+    } else if constexpr (R == 3) {
+        dft3(v[0], v[1], v[2]);
+    } else if constexpr (R == 4) {
+        dft4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (R == 5) {
+        dft5(v[0], v[1], v[2], v[3], v[4]);
+    } else {
+        constexpr int Ra = (R % 5 == 0) ? 5 : (R % 4 == 0) ? 4 : (R % 3 == 0) ? 3 : 2;
+        constexpr int Rb = R / Ra;
+        static_assert(Ra * Rb == R && Rb > 1, "radix must be 2-3-5 smooth");
+        float2 y[R];
+#pragma unroll
+        for (int n2 = 0; n2 < Rb; ++n2) {
+            float2 t[Ra];
+#pragma unroll
+            for (int n1 = 0; n1 < Ra; ++n1) t[n1] = v[Rb * n1 + n2];
+            dft_nat<Ra>(t);
+#pragma unroll
+            for (int k1 = 0; k1 < Ra; ++k1) {
+                const int m = (n2 * k1) % R;
+                if (m == 0) {
+                    y[k1 * Rb + n2] = t[k1];
+                } else {
+                    const double a = -6.28318530717958647692 * (double)m / (double)R;
+                    y[k1 * Rb + n2] = cmul(t[k1], make_float2((float)__builtin_cos(a), (float)__builtin_sin(a)));
+                }
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < Ra; ++k1) {
+            dft_nat<Rb>(&y[k1 * Rb]);
+#pragma unroll
+            for (int k2 = 0; k2 < Rb; ++k2) v[k1 + Ra * k2] = y[k1 * Rb + k2];
+        }
+    }
+}
+
 // Composite radices: R = R1 * R2, input q = q1 R2 + q2, output q' = k1 + R1 k2:
 // R2 DFTs of length R1, constant twiddles W_R^(q2 k1), R1 DFTs of length R2.
 
@@ -214,6 +260,7 @@ __device__ __forceinline__ void dif_stage(float2* tile, const float2* tw, int L,
         if constexpr (R == 6) dft6(v);
         if constexpr (R == 8) dft8(v);
         if constexpr (R == 10) dft10(v);
+        if constexpr (R > 10) dft_nat<R>(v);
         const int tstep = kp * step;
 #pragma unroll
         for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[q * tstep]);
@@ -361,6 +408,10 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             case 5: dif_stage<5>(tile, tw, L, mt, swz); break;
             case 6: dif_stage<6>(tile, tw, L, mt, swz); break;
             case 8: dif_stage<8>(tile, tw, L, mt, swz); break;
+            case 20: dif_stage<20>(tile, tw, L, mt, swz); break;
+            case 24: dif_stage<24>(tile, tw, L, mt, swz); break;
+            case 25: dif_stage<25>(tile, tw, L, mt, swz); break;
+            case 32: dif_stage<32>(tile, tw, L, mt, swz); break;
             default: dif_stage<10>(tile, tw, L, mt, swz); break;
         }
         mt /= r;
@@ -461,6 +512,7 @@ __device__ __forceinline__ void dft_p(float2* v) {
     if constexpr (R == 6) dft6p(v);
     if constexpr (R == 8) dft8p(v);
     if constexpr (R == 10) dft10p(v);
+    if constexpr (R > 10 || R == 7 || R == 9) dft_nat<R>(v);
 }
 
 // RCFM_FFT_ROWS_PITCH17 (default): rows-type tiles use a padded pitch of 17 points instead of the XOR
@@ -1322,7 +1374,20 @@ struct StorePlainT {
 
 // Lengths with a compile-time specialisation (radices listed first stage first; they must
 // match choose_radices() in fft_engine.hip).  Other lengths run the generic kernel.
-#define RCFM_FFT_FAST_LENGTHS(X) \
+// RCFM_FFT_TWO_STAGE: the 480..640-point tiles as two LDS stages of composite radices (dft_nat).
+#ifndef RCFM_FFT_TWO_STAGE
+#define RCFM_FFT_TWO_STAGE 1
+#endif
+#define RCFM_FFT_LONG_TABLE3(X) X(480, 10, 8, 6, 1) X(500, 10, 10, 5, 1)
+#if RCFM_FFT_TWO_STAGE
+#define RCFM_FFT_LONG_TABLE(X) X(480, 24, 20, 1, 1) X(500, 25, 20, 1, 1)
+#else
+#define RCFM_FFT_LONG_TABLE(X) RCFM_FFT_LONG_TABLE3(X)
+#endif
+// Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.  Two stages of radix 24..32 leave
+// 60 % of the 1024 threads idle and measured slower here (3.1 vs 2.75 ms at N = 2.4e8).
+#define RCFM_FFT_BIG_LENGTHS(X) X(600, 10, 10, 6, 1) X(625, 5, 5, 5, 5) X(640, 10, 8, 8, 1)
+#define RCFM_FFT_LENGTHS_(X, LONGT) \
     X(75, 5, 5, 3, 1)            \
     X(80, 10, 8, 1, 1)           \
     X(100, 10, 10, 1, 1)         \
@@ -1341,15 +1406,13 @@ struct StorePlainT {
     X(375, 5, 5, 5, 3)           \
     X(384, 8, 8, 6, 1)           \
     X(400, 10, 10, 4, 1)         \
-    X(480, 10, 8, 6, 1)          \
-    X(500, 10, 10, 5, 1)         \
+    LONGT(X)                     \
     X(512, 8, 8, 8, 1)
+#define RCFM_FFT_FAST_LENGTHS(X) RCFM_FFT_LENGTHS_(X, RCFM_FFT_LONG_TABLE)
+// k_fft_tile2_pair keeps RL points per last-stage butterfly row in registers next to the point-wise
+// stage's inputs: with a last radix of 20 it spills, so it stays on three stages.
+#define RCFM_FFT_PAIR_LENGTHS(X) RCFM_FFT_LENGTHS_(X, RCFM_FFT_LONG_TABLE3)
 
-// Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.
-#define RCFM_FFT_BIG_LENGTHS(X) \
-    X(600, 10, 10, 6, 1)        \
-    X(625, 5, 5, 5, 5)          \
-    X(640, 10, 8, 8, 1)
 
 // Threads per tile.  Long tiles are LDS-limited to two workgroups per CU; 512 threads keep
 // 16 waves per CU in flight there (build with -DRCFM_FFT_LONG_THREADS=256 to compare).
@@ -1445,8 +1508,13 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
 
 // Spectral decimation between two transforms (k_fft_tile2_decim): (long last-pass length, short
 // first-pass length) pairs with an instantiation.
+#if RCFM_FFT_TWO_STAGE
+#define RCFM_FFT_DECIM_500(X) X(500, 25, 20, 1, 1, 100, 10, 10)
+#else
+#define RCFM_FFT_DECIM_500(X) X(500, 10, 10, 5, 1, 100, 10, 10)
+#endif
 #define RCFM_FFT_DECIM_PAIRS(X)          \
-    X(500, 10, 10, 5, 1, 100, 10, 10)    \
+    RCFM_FFT_DECIM_500(X)                \
     X(125, 5, 5, 5, 1, 80, 10, 8)
 
 inline bool fft_tile2_decim_applies(const FftPassDev& d1, const FftPassDev& d2, int batch) {
@@ -1491,7 +1559,7 @@ inline bool launch_fft_tile2_pair(const FftPassDev& d1, const FftPassDev& d2, in
         hipLaunchKernelGGL((k_fft_tile2_pair<LEN, A, B, C, D, tile_threads(LEN), LoadOp, MidOp, StoreOp>), grid, \
                            dim3(tile_threads(LEN)), 0, s, d1, d2, ld, mid, st, count);                           \
         break;
-        RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
+        RCFM_FFT_PAIR_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
         default: return false;
     }
