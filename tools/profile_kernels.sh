@@ -16,5 +16,5 @@ else
     csv=$(find "$out" -name '*kernel_stats.csv' | head -1)
     cp "$csv" "$root/gpurun_out/${tag}_kernel_stats.csv"
 fi
-tail -1 "$out/bench.log" > "$root/gpurun_out/${tag}_bench.json"
+grep "^{\"metric\"" "$out/bench.log" | tail -1 > "$root/gpurun_out/${tag}_profiled_bench.json"
 find "$out" -type f -size +8M -delete
