@@ -408,6 +408,9 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             case 5: dif_stage<5>(tile, tw, L, mt, swz); break;
             case 6: dif_stage<6>(tile, tw, L, mt, swz); break;
             case 8: dif_stage<8>(tile, tw, L, mt, swz); break;
+            case 12: dif_stage<12>(tile, tw, L, mt, swz); break;
+            case 15: dif_stage<15>(tile, tw, L, mt, swz); break;
+            case 16: dif_stage<16>(tile, tw, L, mt, swz); break;
             case 20: dif_stage<20>(tile, tw, L, mt, swz); break;
             case 24: dif_stage<24>(tile, tw, L, mt, swz); break;
             case 25: dif_stage<25>(tile, tw, L, mt, swz); break;
@@ -1387,6 +1390,31 @@ struct StorePlainT {
 // Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.  Two stages of radix 24..32 leave
 // 60 % of the 1024 threads idle and measured slower here (3.1 vs 2.75 ms at N = 2.4e8).
 #define RCFM_FFT_BIG_LENGTHS(X) X(600, 10, 10, 6, 1) X(625, 5, 5, 5, 5) X(640, 10, 8, 8, 1)
+#if RCFM_FFT_TWO_STAGE
+// Two stages wherever both keep at least ~60 % of the threads on a butterfly (L / R >= 10 rows of 16 lanes
+// for 256 threads, >= 19 for 512); 125 as 25 x 5 (5 rows) measured 4 % slower on cfg5.
+#define RCFM_FFT_LENGTHS_(X, LONGT) \
+    X(75, 5, 5, 3, 1)            \
+    X(80, 10, 8, 1, 1)           \
+    X(100, 10, 10, 1, 1)         \
+    X(120, 12, 10, 1, 1)         \
+    X(125, 5, 5, 5, 1)           \
+    X(128, 8, 8, 2, 1)           \
+    X(150, 15, 10, 1, 1)         \
+    X(160, 16, 10, 1, 1)         \
+    X(192, 16, 12, 1, 1)         \
+    X(200, 20, 10, 1, 1)         \
+    X(240, 24, 10, 1, 1)         \
+    X(250, 25, 10, 1, 1)         \
+    X(256, 16, 16, 1, 1)         \
+    X(300, 20, 15, 1, 1)         \
+    X(320, 10, 8, 4, 1)          \
+    X(375, 5, 5, 5, 3)           \
+    X(384, 8, 8, 6, 1)           \
+    X(400, 20, 20, 1, 1)         \
+    LONGT(X)                     \
+    X(512, 8, 8, 8, 1)
+#else
 #define RCFM_FFT_LENGTHS_(X, LONGT) \
     X(75, 5, 5, 3, 1)            \
     X(80, 10, 8, 1, 1)           \
@@ -1408,6 +1436,7 @@ struct StorePlainT {
     X(400, 10, 10, 4, 1)         \
     LONGT(X)                     \
     X(512, 8, 8, 8, 1)
+#endif
 #define RCFM_FFT_FAST_LENGTHS(X) RCFM_FFT_LENGTHS_(X, RCFM_FFT_LONG_TABLE)
 // k_fft_tile2_pair keeps RL points per last-stage butterfly row in registers next to the point-wise
 // stage's inputs: with a last radix of 20 it spills, so it stays on three stages.
@@ -1510,12 +1539,14 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
 // first-pass length) pairs with an instantiation.
 #if RCFM_FFT_TWO_STAGE
 #define RCFM_FFT_DECIM_500(X) X(500, 25, 20, 1, 1, 100, 10, 10)
+#define RCFM_FFT_DECIM_125(X) X(125, 5, 5, 5, 1, 80, 10, 8)
 #else
 #define RCFM_FFT_DECIM_500(X) X(500, 10, 10, 5, 1, 100, 10, 10)
+#define RCFM_FFT_DECIM_125(X) X(125, 5, 5, 5, 1, 80, 10, 8)
 #endif
 #define RCFM_FFT_DECIM_PAIRS(X)          \
     RCFM_FFT_DECIM_500(X)                \
-    X(125, 5, 5, 5, 1, 80, 10, 8)
+    RCFM_FFT_DECIM_125(X)
 
 inline bool fft_tile2_decim_applies(const FftPassDev& d1, const FftPassDev& d2, int batch) {
     bool fast = false;

@@ -20,7 +20,7 @@ def test_lengths_of_the_hot_path_are_planned():
             prod *= p.L
             r = 1
             for s in range(p.nstages):
-                assert p.radix[s] in (2, 3, 4, 5, 6, 8, 10, 20, 24, 25, 32)   # 20..32: in-register composites
+                assert p.radix[s] in (2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 24, 25, 32)   # 20..32: in-register composites
                 r *= p.radix[s]
             # 512 = two workgroups per CU; up to 640 (one workgroup per CU) only where that saves a pass
             assert r == p.L and 16 <= p.L <= (640 if n == 240_000_000 else 512)
