@@ -35,6 +35,18 @@ def test_engine_matches_numpy(n, batch, inverse):
         assert rel_err(_run(n, batch, inverse, x, in_place=True), want.astype(np.complex64)) <= 2e-6
 
 
+@pytest.mark.parametrize("n", [24000, 49152, 96000, 144000, 204800])
+def test_every_specialised_tile_length(n):
+    """The remaining tile lengths with a compile-time kernel (150/160, 192/256, 300/320, 375/384, 400/512),
+    each as the strided pass of one plan and the rows pass of its transpose."""
+    r = np.random.default_rng(n)
+    x = (r.standard_normal((2, n)) + 1j * r.standard_normal((2, n))).astype(np.complex64)
+    want = np.fft.fft(x.astype(np.complex128), axis=1).astype(np.complex64)
+    assert rel_err(_run(n, 2, False, x), want) <= 2e-6
+    back = _run(n, 2, True, want)
+    assert rel_err(back, x * n) <= 4e-6
+
+
 def test_engine_impulse_and_tone_are_exact_enough():
     """Transpose-detecting inputs: a shifted impulse and a single off-centre tone."""
     n = 240000
