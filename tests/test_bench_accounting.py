@@ -1,0 +1,40 @@
+"""CPU: the algorithmic-byte accounting bench.py reports against and the
+channel grids of its configs (the padded-span rule of tuner.py:163-174)."""
+
+import sys
+
+from conftest import ROOT
+
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_path_bytes_match_the_survey_totals():
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg4"]
+    assert kind == "WBFM"
+    total = bench.path_bytes(N, C, B, A, kind)
+    assert abs(total - 21.53e9) < 0.01e9              # 3.84 GB + 1024 x 17.28 MB
+    assert abs(total / N - 89.7) < 0.1                # bytes per input sample
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg5"]
+    assert abs(bench.path_bytes(N, C, B, A, kind) - 4.84e9) < 0.01e9
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg3"]
+    assert abs(bench.path_bytes(N, C, B, A, kind) - 590e6) < 1e6
+
+
+def test_stage_bytes_cover_the_path():
+    """The per-stage table adds up to the per-channel totals (WBFM: 16B tuner + 48B + 40A)."""
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg4"]
+    assert bench.stage_bytes("tuner_fft_N", N, B, A, kind) == 16 * N
+    assert bench.stage_bytes("tuner_ifft_B", N, B, A, kind) == 16 * B
+    wbfm = sum(bench.stage_bytes(k, N, B, A, kind) for k in
+               ("pilot_stage", "rfft_B", "ifft_B", "fft_B"))
+    assert wbfm <= 48 * B + 20 * B                    # the FFT stages of the chain, each read + write once
+
+
+def test_channel_grids_fit_the_wideband_buffer():
+    for name, (N, C, B, _A, raster, _kind) in bench.CONFIGS.items():
+        span = (C - 1) * raster + B
+        pad = (-span) % (C * B // C)                  # tuner.py:170: span padded to a multiple of the mean bandwidth
+        assert span + pad <= N, name
