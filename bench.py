@@ -221,6 +221,7 @@ def main():
     bw_a = (ctypes.c_int32 * C)(*([B] * C))
     tuner = ctypes.c_void_p()
     hip.check(lib.rcfm_tuner_create(N, C, roll_a, bw_a, ctypes.byref(tuner)))
+    hip.check(lib.rcfm_tuner_shard(tuner, lo, mine))   # the wideband FFT keeps only what this rank's channels read
     demod = ctypes.c_void_p()
     kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
     hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))

@@ -79,6 +79,11 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
                       rcfm_tuner_t* out);
 /* Tuner.load, tuner.py:126-138: X = FFT_n(x), kept by the handle. x: [n] complex64. */
 int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream);
+/* Multi-GPU sharding (no reference counterpart: the reference has one device; its loop over all channels is
+ * examples/multi_fm_server.py:100-106).  A rank that will only run channels [first, first + count) declares
+ * it before rcfm_tuner_load: the last pass of the wideband FFT then stores only the part of the spectrum
+ * those channels read (the other bins of the kept spectrum are undefined).  Default: every channel. */
+int rcfm_tuner_shard(rcfm_tuner_t t, int first, int count);
 /* Tuner.run for channels [first, first+count), tuner.py:140-161: circular shift
  * by roll, fftshifted-Hann weight, brick-wall truncation to bw bins, inverse
  * FFT, x bw/n.  All channels of the range must share one bandwidth B;

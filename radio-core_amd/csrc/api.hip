@@ -261,6 +261,41 @@ struct rcfm_tuner_s {
     DeviceBuffer forward_tmp;                  // engine: the last pass cannot run in place
     DeviceBuffer band_tmp;
     bool loaded = false;
+    // rcfm_tuner_shard: rows of the spectrum (FftRowWindow) the declared channel range reads
+    bool windowed = false;
+    FftRowWindow window{0, 0};
+
+    void shard(int first, int count) {
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
+        windowed = false;
+        if (!forward_engine || count == 0) return;
+        const int64_t f0 = forward_engine->row_length();
+        const int64_t rows = n / f0;
+        if (rows < 64) return;
+        std::vector<char> used((size_t)rows, 0);
+        for (int c = first; c < first + count; ++c) {
+            const int64_t centre = (n - roll[c]) % n, h = bw[c] / 2 + 2;
+            const int64_t r0 = (centre - h) / f0 - ((centre - h) < 0 ? 1 : 0), r1 = (centre + h) / f0;
+            for (int64_t r = r0; r <= r1; ++r) used[(size_t)(((r % rows) + rows) % rows)] = 1;
+        }
+        // the longest circular run of unused rows is dropped; everything else is kept
+        int64_t best_len = 0, best_start = 0, run = 0;
+        for (int64_t i = 0; i < 2 * rows; ++i) {
+            if (!used[(size_t)(i % rows)]) {
+                ++run;
+                if (run > best_len && run <= rows) {
+                    best_len = run;
+                    best_start = i - run + 1;
+                }
+            } else {
+                run = 0;
+            }
+        }
+        if (best_len < rows / 64 || best_len >= rows) return;   // nothing worth skipping (or nothing used)
+        window.lo = (int)((best_start + best_len) % rows);
+        window.hi = (int)(((best_start - 1) % rows + rows) % rows);
+        windowed = true;
+    }
     struct Band {
         ResampleGeom geom;
         PlanCache inverse;
@@ -783,7 +818,7 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
             StageTimer tm(ST_TUNER_FFT, as_stream(stream));
             if (t->forward_engine) {
                 t->forward_engine->c2c(static_cast<const float2*>(x), t->spectrum(), t->forward_tmp.as<float2>(),
-                                       1, false, 1.0f, as_stream(stream));
+                                       1, false, 1.0f, as_stream(stream), t->windowed ? &t->window : nullptr);
             } else {
                 t->work.reserve(t->forward->work_bytes());
                 t->forward->exec(const_cast<void*>(x), t->spectrum(), t->work.get(), as_stream(stream));
@@ -796,6 +831,13 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
             }
         }
         t->loaded = true;
+    });
+}
+
+int rcfm_tuner_shard(rcfm_tuner_t t, int first, int count) {
+    return guarded([&] {
+        RC_REQUIRE(t != nullptr, RCFM_ERR_ARG, "NULL argument");
+        t->shard(first, count);
     });
 }
 

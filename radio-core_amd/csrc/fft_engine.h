@@ -78,6 +78,12 @@ struct FftPassDev {
     int debug;                // RCFM_FFT_DEBUG bit mask: timing experiments only (wrong results)
 };
 
+// Rows of the transform's output to keep (row r = output elements [r n_1, (r+1) n_1), n_1 = the plan's first
+// pass length): lo <= hi keeps rows lo..hi, lo > hi keeps rows >= lo and rows <= hi (a window that wraps).
+struct FftRowWindow {
+    int lo, hi;
+};
+
 class FftEngine {
    public:
     explicit FftEngine(int64_t n);
@@ -90,8 +96,11 @@ class FftEngine {
     // Unnormalised c2c transform of `batch` contiguous length-n signals (distance n).
     // `tmp` holds batch * tmp_stride() complex values; in == out is allowed, tmp must be distinct.
     // inverse = conjugate transform (no 1/n); every output is multiplied by `scale`.
+    // keep (forward transforms only): the last pass stores only those rows of the output; the rest of
+    // `out` is left untouched.
     void c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
-             hipStream_t stream) const;
+             hipStream_t stream, const FftRowWindow* keep = nullptr) const;
+    int64_t row_length() const { return desc_.pass[0].L; }   // n_1
     FftPassDev pass_dev(int t, int64_t in_batch, int64_t out_batch) const;
     static size_t lds_bytes(int L);
     static dim3 grid(const FftPass& p, int batch);

@@ -334,7 +334,7 @@ FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch) const
 }
 
 void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
-                    hipStream_t stream) const {
+                    hipStream_t stream, const FftRowWindow* keep) const {
     if (batch <= 0) return;
     const int np = desc_.npass;
     const int64_t n = desc_.n;
@@ -348,6 +348,10 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
             LoadPlainT<false> ld{src};
             if (inverse)
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<true>{out, scale}, stream);
+            else if (keep != nullptr)
+                launch_fft_pass<kRowsOnly>(dev, batch, ld,
+                                           StoreRowWindow{out, scale, (int)dev.p.n_o1, (int)dev.p.n_o2, keep->lo, keep->hi},
+                                           stream);
             else
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<false>{out, scale}, stream);
         } else {

@@ -1375,6 +1375,19 @@ struct StorePlainT {
     }
 };
 
+// Last pass of a forward transform of which only a window of output rows is wanted (FftRowWindow): row =
+// o1 + n_o1 (o2 + n_o2 k) in the last pass's line coordinates.
+struct StoreRowWindow {
+    float2* out;
+    float scale;
+    int n_o1, n_o2, lo, hi;
+    __device__ __forceinline__ void operator()(const LineId& id, int k, int64_t base, unsigned off, float2 v) const {
+        const int row = (int)id.o1 + n_o1 * ((int)id.o2 + n_o2 * k);
+        const bool keep = lo <= hi ? (row >= lo && row <= hi) : (row >= lo || row <= hi);
+        if (keep) stream_store(out + base + off, make_float2(v.x * scale, v.y * scale));
+    }
+};
+
 // Lengths with a compile-time specialisation (radices listed first stage first; they must
 // match choose_radices() in fft_engine.hip).  Other lengths run the generic kernel.
 // RCFM_FFT_TWO_STAGE: the 480..640-point tiles as two LDS stages of composite radices (dft_nat).
@@ -1459,6 +1472,7 @@ constexpr int tile_threads(int L) {
 template <class T> struct is_plain_functor : std::false_type {};
 template <bool S> struct is_plain_functor<LoadPlainT<S>> : std::true_type {};
 template <bool S> struct is_plain_functor<StorePlainT<S>> : std::true_type {};
+template <> struct is_plain_functor<StoreRowWindow> : std::true_type {};
 
 // Which pass kinds a functor pair is ever used with (prunes template instantiations).
 enum PassKinds : int { kAnyPass = 0, kStridedOnly = 1, kRowsOnly = 2 };

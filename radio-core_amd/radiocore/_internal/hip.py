@@ -39,6 +39,7 @@ SIGNATURES = {
     "rcfm_stream_sync": [_vp],
     "rcfm_tuner_create": [_i64, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp)],
     "rcfm_tuner_load": [_vp, _vp, _vp],
+    "rcfm_tuner_shard": [_vp, _i, _i],
     "rcfm_tuner_run": [_vp, _i, _i, _vp, _vp],
     "rcfm_tuner_spectrum": [_vp, ctypes.POINTER(_vp)],
     "rcfm_tuner_destroy": [_vp],

@@ -50,6 +50,7 @@ class Tuner(Injector):
         self._bounds: List[Channel] = []
         self._handle = None        # librcfm tuner, rebuilt when the geometry changes
         self._handle_key = None
+        self._shard = None         # (first, count) declared by shard()
         self._loaded_size = None
         self._batched = None       # (key, demod handle) of run_all
 
@@ -115,7 +116,19 @@ class Tuner(Injector):
             self._handle = hip.Handle(h, self._lib.rcfm_tuner_destroy)
             self._handle_key = key
             self._loaded_size = None
+            if self._shard is not None:
+                hip.check(self._lib.rcfm_tuner_shard(h, self._shard[0], self._shard[1]))
         return self._handle.value
+
+    def shard(self, first, count):
+        """Multi-GPU only (no reference counterpart): this process will run channels
+        [first, first + count) and nothing else, so `load` may keep just the part of the spectrum
+        they read (sharding.channel_range gives the range of a rank)."""
+        if first < 0 or count < 0 or first + count > len(self._bounds):
+            raise IndexError("channel range outside the tuner")
+        self._shard = (int(first), int(count))
+        if self._handle is not None:
+            hip.check(self._lib.rcfm_tuner_shard(self._handle.value, int(first), int(count)))
 
     def load(self, input_signal):
         """Forward FFT of the one-second buffer; kept on the device (tuner.py:126-138)."""

@@ -146,6 +146,33 @@ def test_narrow_channels_take_the_haloed_gather(rc, oracle):
         assert rel_err(audio[ch.index], ch.demodulator.run(iq)[0]) <= TOL, ch.index
 
 
+def test_sharded_tuner_keeps_what_its_channels_read(rc, oracle):
+    """Tuner.shard(first, count): the wideband FFT stores only the rows of the spectrum the declared channels
+    read; their outputs do not change (every rank of a multi-GPU run works like this)."""
+    N, B, A, C = 6_000_000, 60000, 12000, 8
+    centres = workloads.channel_grid(C, 700000)          # spread over the band: a shard needs a fraction of it
+    full, part = rc.Tuner(), rc.Tuner()
+    ref = oracle.Tuner()
+    for f in centres:
+        full.add_channel(f, B, rc.MFM(B, A))
+        part.add_channel(f, B, rc.MFM(B, A))
+        ref.add_channel(f, B, None)
+    for t in (full, part, ref):
+        t.request_bandwidth(float(N))
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.35)
+    ref.load(x)
+    for first, count in ((0, 3), (5, 3), (3, 2)):
+        part.shard(first, count)
+        part.load(x)
+        full.load(x)
+        for i in range(first, first + count):
+            iq = ref.run_pruned(i)
+            assert rel_err(part.run(i), iq) <= TOL, (first, i)
+            assert np.array_equal(part.run(i), full.run(i)), (first, i)
+    with pytest.raises(IndexError):
+        part.shard(6, 3)
+
+
 def test_tuner_spectrum_bins(rc, golden):
     """Tuner.load keeps FFT_N(x): spot bins against the reference's."""
     g = golden("tuner")
