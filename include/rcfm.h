@@ -82,7 +82,9 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream);
 /* Multi-GPU sharding (no reference counterpart: the reference has one device; its loop over all channels is
  * examples/multi_fm_server.py:100-106).  A rank that will only run channels [first, first + count) declares
  * it before rcfm_tuner_load: the last pass of the wideband FFT then stores only the part of the spectrum
- * those channels read (the other bins of the kept spectrum are undefined).  Default: every channel. */
+ * those channels read (the other bins of the kept spectrum are undefined).  Default: every channel.
+ * rcfm_tuner_run / rcfm_pipeline_run remember the range that was in force at load time and fail with
+ * RCFM_ERR_STATE for a channel outside it; a new range takes effect with the next rcfm_tuner_load. */
 int rcfm_tuner_shard(rcfm_tuner_t t, int first, int count);
 /* Tuner.run for channels [first, first+count), tuner.py:140-161: circular shift
  * by roll, fftshifted-Hann weight, brick-wall truncation to bw bins, inverse

@@ -264,10 +264,17 @@ struct rcfm_tuner_s {
     // rcfm_tuner_shard: rows of the spectrum (FftRowWindow) the declared channel range reads
     bool windowed = false;
     FftRowWindow window{0, 0};
+    int shard_first = 0, shard_count = 0;        // the declared range (valid while windowed)
+    // what the spectrum in X was loaded for: a windowed load stores only the rows [loaded_first,
+    // loaded_first + loaded_count) reads, so run() refuses channels outside it (the other bins are stale)
+    bool loaded_windowed = false;
+    int loaded_first = 0, loaded_count = 0;
 
     void shard(int first, int count) {
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
         windowed = false;
+        shard_first = first;
+        shard_count = count;
         if (!forward_engine || count == 0) return;
         const int64_t f0 = forward_engine->row_length();
         const int64_t rows = n / f0;
@@ -322,6 +329,9 @@ struct rcfm_tuner_s {
     void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr) {
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
         RC_REQUIRE(loaded, RCFM_ERR_STATE, "rcfm_tuner_run called before rcfm_tuner_load");
+        RC_REQUIRE(!loaded_windowed || (first >= loaded_first && first + count <= loaded_first + loaded_count),
+                   RCFM_ERR_STATE,
+                   "channel outside the shard the spectrum was loaded for (rcfm_tuner_shard, then rcfm_tuner_load)");
         if (count == 0) return;
         const int32_t B = bw[first];
         for (int i = 0; i < count; ++i)
@@ -831,6 +841,9 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
             }
         }
         t->loaded = true;
+        t->loaded_windowed = t->forward_engine && t->windowed;
+        t->loaded_first = t->shard_first;
+        t->loaded_count = t->shard_count;
     });
 }
 

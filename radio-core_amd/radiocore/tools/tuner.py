@@ -170,6 +170,9 @@ class Tuner(Injector):
         de-emphasis state of this batched path lives in the tuner (one state per
         channel, carried from buffer to buffer) and is independent of the
         per-channel demodulator instances.
+
+        After ``shard(first, count)`` only that range is run (its spectrum rows are all ``load``
+        kept) and the result is [count, A, ch] -- the block sharding.gather_audio expects.
         """
         handle = self._ready()
         demods = [ch.demodulator for ch in self._bounds]
@@ -186,7 +189,8 @@ class Tuner(Injector):
             hip.check(self._lib.rcfm_demod_create(kind, C, B, A, tau, int(chunk), ctypes.byref(h)))
             self._batched = (key, hip.Handle(h, self._lib.rcfm_demod_destroy))
         ch = 2 if kind == hip.RCFM_WBFM else 1
-        audio = hip.empty((C, A, ch), self._torch.float32)
-        hip.check(self._lib.rcfm_pipeline_run(handle, self._batched[1].value, 0, C, hip.ptr(audio),
+        first, count = self._shard if self._shard is not None else (0, C)
+        audio = hip.empty((count, A, ch), self._torch.float32)
+        hip.check(self._lib.rcfm_pipeline_run(handle, self._batched[1].value, first, count, hip.ptr(audio),
                                               hip.stream()))
         return self._result(audio, self._cuda and not numpy_output)

@@ -1,0 +1,196 @@
+"""GPU: the batched caller (Tuner.run_all -> rcfm_pipeline_run) on every BASELINE.json GPU configuration.
+
+Reference caller: examples/multi_fm_server.py:98-106 (load, then run -> demodulator.run per channel) with
+radiocore/analog/fm.py:60-67, mfm.py:62-66, wbfm.py:66-105 behind it.  Reduced sizes run every channel and two
+buffers (state carry) against the oracle loop; the full geometries of cfg3 / cfg4 / cfg5 (BASELINE.json
+configs[2..4]) check a sample of channels against the oracle fed with the same wideband buffer, plus
+size-independent properties (Parseval on the stored spectrum, idempotence of a second identical buffer for the
+state-free FM path, bounded clipped output).
+
+Tolerance: max|delta| <= 1e-4 * max|expected| (BASELINE.json north star), float32 end to end.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+import workloads
+from conftest import TOL, have_gpu, rel_err
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs an MI355X")]
+
+
+@pytest.fixture(scope="module")
+def rc():
+    import radiocore
+    assert radiocore.HasCuda(), "librcfm.so did not load or sees no device"
+    return radiocore
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import radiocore_oracle
+    return radiocore_oracle
+
+
+def _pair(rc, oracle, kind, centres, B, A, N):
+    tuner, ref = rc.Tuner(), oracle.Tuner()
+    for f in centres:
+        tuner.add_channel(f, B, getattr(rc, kind)(B, A))
+        ref.add_channel(f, B, getattr(oracle, kind)(B, A))
+    tuner.request_bandwidth(float(N))
+    ref.request_bandwidth(float(N))
+    assert tuner.input_frequency == ref.input_frequency
+    return tuner, ref
+
+
+# ---- reduced size: every channel, two buffers, ragged chunks --------------------------------------
+
+@pytest.mark.parametrize("kind,chunk", [("FM", 3), ("MFM", 3), ("WBFM", 3), ("FM", 4), ("MFM", 0), ("MFM", 1)])
+def test_run_all_every_demodulator(rc, oracle, kind, chunk):
+    """Odd channel count; chunk 3 leaves chunks of 3 + 3 + 1 (a lone member in every chunk's last pair and a
+    one-channel remainder), chunk 4 gives 4 + 3, chunk 1 runs every pair kernel with a single member.
+    The second buffer checks the de-emphasis state carried per channel (first * ch * 50 offsets)."""
+    N, B, A, C = 1_200_000, 60000, 12000, 7
+    centres = workloads.channel_grid(C, 50000)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    stereo = kind == "WBFM"
+    for buf in range(2):
+        x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.35, stereo=stereo)
+        x = np.roll(x, 4321 * buf)
+        tuner.load(x)
+        ref.load(x)
+        audio = tuner.run_all(chunk=chunk)
+        ch = 2 if stereo else 1
+        assert audio.shape == (C, A, ch) and audio.dtype == np.float32
+        for c in ref.channels():
+            want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, ch)
+            assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index)
+
+
+@pytest.mark.parametrize("A", [12150, 12006])
+@pytest.mark.parametrize("kind", ["FM", "MFM"])
+def test_run_all_a_not_multiple_of_four(rc, oracle, kind, A):
+    """A % 4 != 0 takes MFM off the packed-pair decimation (api.hip run_chunk) onto the generic de-emphasis
+    kernels.  A = 12150 = 2 * 3^5 * 5^2 stays on the FFT engine but is no tile-aligned decimation of B = 60000
+    (pair FFT -> full spectrum -> unpack -> real-output inverse FFT); A = 12006 has the prime factors 23 and 29:
+    every transform of the demodulator goes through rocFFT."""
+    N, B, C = 1_200_000, 60000, 3
+    centres = workloads.channel_grid(C, 70000)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    for buf in range(2):
+        x = np.roll(workloads.wideband(N, ref.input_frequency, centres, B, gain=0.35, stereo=False), 99 * buf)
+        tuner.load(x)
+        ref.load(x)
+        audio = tuner.run_all()
+        for c in ref.channels():
+            want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, 1)
+            assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index)
+
+
+def test_run_all_narrowband_fm_geometry(rc, oracle):
+    """cfg5's channel geometry (12.5 kHz FM channels -> 8 kHz audio: B = 12 500 = 100 x 125, the 125 -> 80
+    decimating tile) at a reduced band: N = 1e6, 81 channels on the 12 kHz raster, default chunk."""
+    N, B, A, C = 1_000_000, 12500, 8000, 81
+    centres = workloads.channel_grid(C, 12000)
+    tuner, ref = _pair(rc, oracle, "FM", centres, B, A, N)
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.1, stereo=False, deviation=2500.0)
+    tuner.load(x)
+    ref.load(x)
+    audio = tuner.run_all()
+    assert audio.shape == (C, A, 1)
+    for c in ref.channels():
+        iq = ref.run_pruned(c.index)
+        if c.index in (0, 40, 80):
+            assert rel_err(tuner.run(c.index), iq) <= TOL, c.index
+        want = np.asarray(c.demodulator.run(iq)).reshape(A, 1)
+        assert rel_err(audio[c.index], want) <= TOL, c.index
+
+
+# ---- full geometries --------------------------------------------------------------------------------
+
+def _full_config(rc, oracle, name, sample, buffers=1):
+    """Runs BASELINE config `name` at full size on the GPU; returns per sampled channel the worst error of
+    the audio against the oracle (over `buffers` consecutive buffers) and the tuner's IQ error."""
+    import torch
+    import bench
+    import workloads_device
+    from radiocore._internal import hip
+    N, C, B, A, raster, kind = bench.CONFIGS[name]
+    lib = hip.lib()
+    x, centres, f_in = workloads_device.synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
+    tuner = rc.Tuner()
+    for f in centres:
+        tuner.add_channel(f, B, getattr(rc, kind)(B, A))
+    tuner.request_bandwidth(float(N))
+    assert tuner.input_frequency == f_in
+    ref = oracle.Tuner()
+    for f in centres:
+        ref.add_channel(f, B, None)
+    ref.request_bandwidth(float(N))
+    demods = {i: getattr(oracle, kind)(B, A) for i in sample}
+    ch = 2 if kind == "WBFM" else 1
+    errs = {i: 0.0 for i in sample}
+    iq_err = 0.0
+    x_host = x.cpu().numpy()
+    for buf in range(buffers):
+        if buf:
+            x = torch.roll(x, 1237 * buf)
+            x_host = np.roll(x_host, 1237 * buf)
+        tuner.load(x)
+        audio = tuner.run_all()
+        assert audio.shape == (C, A, ch) and audio.dtype == np.float32
+        assert np.all(np.isfinite(audio))
+        if kind != "FM":
+            assert float(np.max(np.abs(audio))) <= 0.999 + 1e-6          # np.clip of mfm.py:65 / wbfm.py:100
+        ref.load(x_host)
+        for i in sample:
+            iq = ref.run_pruned(i)
+            if buf == 0:
+                iq_err = max(iq_err, rel_err(tuner.run(i), iq))
+            want = np.asarray(demods[i].run(iq)).reshape(A, ch)
+            errs[i] = max(errs[i], rel_err(audio[i], want))
+    # Parseval on the stored wideband spectrum (size-independent property of Tuner.load)
+    X = ctypes.c_void_p()
+    hip.check(lib.rcfm_tuner_spectrum(tuner._handle.value, ctypes.byref(X)))
+    spec = torch.empty(N, dtype=torch.complex64, device="cuda")
+    hip.check(lib.rcfm_memcpy_d2d(hip.ptr(spec), X, N * 8, hip.stream()))
+    torch.cuda.synchronize()
+    e_t = float(torch.sum(x.real.double() ** 2 + x.imag.double() ** 2))
+    e_f = float(torch.sum(spec.real.double() ** 2 + spec.imag.double() ** 2)) / N
+    assert abs(e_f - e_t) <= 1e-5 * e_t
+    return errs, iq_err, audio, tuner, x
+
+
+def test_cfg3_full_size_mfm(rc, oracle):
+    """BASELINE configs[2]: N = 10 000 000 -> 64 x MFM (240 kHz -> 48 kHz), every 7th channel + the ends,
+    two buffers (de-emphasis state of the batched FM/MFM pipeline)."""
+    sample = sorted(set(range(0, 64, 7)) | {31, 32, 63})
+    errs, iq_err, _, _, _ = _full_config(rc, oracle, "cfg3", sample, buffers=2)
+    print("cfg3", errs, iq_err)
+    assert iq_err <= TOL
+    assert max(errs.values()) <= TOL, errs
+
+
+def test_cfg5_full_size_fm(rc, oracle):
+    """BASELINE configs[4]: N = 100 000 000 -> 8192 x FM (12.5 kHz -> 8 kHz); channels either side of every
+    2048-channel chunk boundary of the default chunking, and the ends.  A second identical load must give
+    bit-identical audio (FM carries no state)."""
+    sample = [0, 1, 2047, 2048, 4095, 4096, 6143, 6144, 8190, 8191]
+    errs, iq_err, audio, tuner, x = _full_config(rc, oracle, "cfg5", sample)
+    print("cfg5", errs, iq_err)
+    assert iq_err <= TOL
+    assert max(errs.values()) <= TOL, errs
+    tuner.load(x)
+    assert np.array_equal(tuner.run_all(), audio)
+
+
+def test_cfg4_full_size_wbfm(rc, oracle):
+    """BASELINE configs[3] (the bench workload): N = 240 000 000 -> 1024 x WBFM; the ends and both sides of
+    the 512-channel chunk boundary."""
+    sample = [0, 511, 512, 1023]
+    errs, iq_err, _, _, _ = _full_config(rc, oracle, "cfg4", sample)
+    print("cfg4", errs, iq_err)
+    assert iq_err <= TOL
+    assert max(errs.values()) <= TOL, errs

@@ -1,0 +1,110 @@
+"""GPU: the channel-sharded HIP path as bench.py --gpus N runs it, on ONE device.
+
+Two processes (world_size 2, gloo rendezvous on 127.0.0.1), both on cuda:0.  Each rank declares its
+channel range (Tuner.shard -> rcfm_tuner_shard: the wideband FFT stores only the spectrum rows the range
+reads), loads the same wideband buffer, runs rcfm_pipeline_run(first = lo, count = n) through
+Tuner.run_all() for two consecutive buffers (per-channel de-emphasis state at offset first * ch * 50),
+moves its block to the host and gathers with sharding.gather_audio.  Rank 0's gathered result must equal a
+single-process run_all(): bit for bit when the shard boundary keeps the channel pairing (even split),
+within float32 rounding otherwise (a channel shares one complex FFT with its pair partner).
+
+Reference loop: examples/multi_fm_server.py:100-106.
+"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TOL, have_gpu, rel_err
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs an MI355X")]
+
+N, B, A = 2_400_000, 60000, 12000
+BUFFERS = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _paths():
+    for p in (ROOT, os.path.join(ROOT, "radio-core_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _inputs(kind, C):
+    import workloads
+    centres = workloads.channel_grid(C, 250000)          # spread: each half of the channels reads part of the band
+    f_in = (min(centres) + max(centres)) / 2
+    x = workloads.wideband(N, f_in, centres, B, gain=0.35, stereo=(kind == "WBFM"))
+    return centres, [np.roll(x, 3111 * b) for b in range(BUFFERS)]
+
+
+def _tuner(rc, kind, centres):
+    t = rc.Tuner()
+    for f in centres:
+        t.add_channel(f, B, getattr(rc, kind)(B, A))
+    t.request_bandwidth(float(N))
+    return t
+
+
+def _worker(rank, world, port, kind, C, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    _paths()
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    import radiocore as rc
+    from radiocore.tools import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    centres, bufs = _inputs(kind, C)
+    lo, hi = sharding.channel_range(rank, world, C)
+    tuner = _tuner(rc, kind, centres)
+    tuner.shard(lo, hi - lo)
+    gathered = []
+    for x in bufs:
+        tuner.load(x)
+        block = tuner.run_all()                            # [hi - lo, A, ch]: only this rank's range runs
+        assert block.shape[0] == hi - lo
+        gathered.append(sharding.gather_audio(torch.from_numpy(block), C, dst=0))
+    # a channel outside the loaded shard is refused, not silently computed from stale spectrum rows
+    other = (hi % C) if hi < C else 0
+    if not (lo <= other < hi):
+        with pytest.raises(RuntimeError, match="outside the shard"):
+            tuner.run(other)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.stack([g.numpy() for g in gathered]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,C,exact", [("WBFM", 8, True), ("MFM", 8, True), ("FM", 7, False)])
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, kind, C, exact):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(2, _free_port(), kind, C, out), nprocs=2, join=True)
+    got = np.load(out)
+    _paths()
+    import radiocore as rc
+    centres, bufs = _inputs(kind, C)
+    tuner = _tuner(rc, kind, centres)
+    for b, x in enumerate(bufs):
+        tuner.load(x)
+        want = tuner.run_all()
+        assert got[b].shape == want.shape
+        if exact:
+            assert np.array_equal(got[b], want), (kind, b, float(np.max(np.abs(got[b] - want))))
+        else:
+            for c in range(C):
+                assert rel_err(got[b][c], want[c]) <= 0.05 * TOL, (kind, b, c)
