@@ -527,14 +527,31 @@ __device__ __forceinline__ void dft_p(float2* v) {
 #endif
 constexpr int kRowsPitch = RCFM_FFT_ROWS_PITCH17 ? W + 1 : W;
 
-template <bool SWZ>
+// P17 = false (big tiles: the whole 80 KiB budget of a workgroup is tile) keeps the XOR swizzle for rows-type
+// tiles: same conflict-free accesses, a few integer instructions per access instead of 1/16 more LDS.
+template <bool SWZ, bool P17 = true>
 __device__ __forceinline__ int lds_slot(int row, int w) {
-    if (SWZ && RCFM_FFT_ROWS_PITCH17) return row * (W + 1) + w;
+    if (SWZ && RCFM_FFT_ROWS_PITCH17 && P17) return row * (W + 1) + w;
     return SWZ ? row * W + (w ^ (row & (W - 1))) : row * W + w;
 }
 
+// Stage twiddles W_L^(q e), q = 1 .. R-1, as powers of one table entry (big tiles keep no copy of the table
+// in LDS: one global load -- an L1 hit, the table is 5 KiB -- per butterfly, then a product tree of depth
+// <= log2 R: w_q = w_hb(q) w_(q - hb(q)), hb = highest power of two <= q).
+template <int R>
+__device__ __forceinline__ void twiddle_powers(float2 w1, float2* pw) {
+    pw[1] = w1;
+#pragma unroll
+    for (int q = 2; q < R; ++q) {
+        int hb = 1;
+        while (hb * 2 <= q) hb *= 2;
+        pw[q] = (hb == q) ? cmul(pw[q / 2], pw[q / 2]) : cmul(pw[hb], pw[q - hb]);
+    }
+}
+
 // Middle stage: LDS -> LDS.  MT = block length entering the stage.
-template <int L, int R, int MT, bool SWZ, int RG>
+// GTW: `tw` is the table in global memory and the q-th twiddle is a power of entry kp * step (twiddle_powers).
+template <int L, int R, int MT, bool SWZ, int RG, bool P17 = true, bool GTW = false>
 __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w, int rg) {
     constexpr int m = MT / R, step = L / MT, rows = L / R, nit = (rows + RG - 1) / RG;
 #pragma unroll
@@ -544,23 +561,46 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
             const int g = b / m, kp = b - g * m;
             const int base = g * MT + kp;
             float2 v[R];
+            float2 pw[GTW ? R : 1];
+            if constexpr (GTW) pw[0] = tw[kp * step];   // issued ahead of the LDS reads it will meet
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<SWZ>(base + q * m, w)];
+            for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<SWZ, P17>(base + q * m, w)];
             dft_p<R>(v);
+            if constexpr (GTW) {
+                twiddle_powers<R>(pw[0], pw);
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], tw[q * kp * step]);
+                for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], pw[q]);
+            } else {
 #pragma unroll
-            for (int q = 0; q < R; ++q) tile[lds_slot<SWZ>(base + q * m, w)] = v[dft_slot<R>(q)];
+                for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], tw[q * kp * step]);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) tile[lds_slot<SWZ, P17>(base + q * m, w)] = v[dft_slot<R>(q)];
         }
     }
 }
+
+// RCFM_FFT_BIG2 (default): the big tiles (600 / 625 / 640 points, 75 .. 80 KiB) run as TWO 1024-thread workgroups
+// per CU (32 waves, <= 64 VGPRs): while one workgroup waits for its tile the other one transforms.
+#ifndef RCFM_FFT_BIG2
+#define RCFM_FFT_BIG2 1
+#endif
+// RCFM_FFT_PAIR2_MIN: shortest tile that runs this way (experiments: 480 moves the 480/500-point tiles over too).
+#ifndef RCFM_FFT_PAIR2_MIN
+#define RCFM_FFT_PAIR2_MIN (kFftMaxL + 1)
+#endif
+constexpr bool big_tile_pair(int L) { return RCFM_FFT_BIG2 && L >= RCFM_FFT_PAIR2_MIN; }
 
 // LoadOp contract:  fetch(id, l, tile_base, off) returns element tile_base + off of the input
 //                   (tile_base is workgroup-uniform, off a 32-bit per-lane offset) and does NO
 //                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
 // StoreOp contract: operator()(id, k, tile_base, off, v).
 template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load, StoreOp store) {
+__global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
+                                                                                          StoreOp store) {
+    // BIG: two 1024-thread workgroups per CU -- the tile is the whole LDS budget of the workgroup (80 KiB), so the
+    // stage twiddles come from the table in global memory (twiddle_powers) and rows tiles use the XOR swizzle.
+    constexpr bool BIG = big_tile_pair(L);
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
     constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;   // last radix
@@ -568,8 +608,9 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     constexpr int RG = T / W;                                  // butterfly rows handled per sweep
     constexpr int nit0 = (m0 + RG - 1) / RG;                   // first-stage butterflies per thread
     constexpr int nld = ROWS ? (L * W + T - 1) / T : nit0 * R0;
-    __shared__ __attribute__((aligned(16))) float2 tile[L * (ROWS ? kRowsPitch : W)];
-    __shared__ __attribute__((aligned(16))) float2 tw[L];
+    __shared__ __attribute__((aligned(16))) float2 tile[L * (ROWS && !BIG ? kRowsPitch : W)];
+    __shared__ __attribute__((aligned(16))) float2 tw_lds[BIG ? 1 : L];
+    const float2* tw = BIG ? d.stage_tw : tw_lds;
     const FftPass& p = d.p;
     const int tid = threadIdx.x;
     const int w = tid & (W - 1), rg = tid >> 4;
@@ -637,7 +678,8 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
             }
         }
     }
-    for (int e = tid; e < L; e += T) tw[e] = d.stage_tw[e];
+    if constexpr (!BIG)
+        for (int e = tid; e < L; e += T) tw_lds[e] = d.stage_tw[e];
     constexpr bool CTX = has_ctx<LoadOp>::value;
     static_assert(!CTX || (!ROWS && NF == 1), "load context: strided single-fetch passes only");
     auto ctx = [&] {
@@ -691,12 +733,12 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
             float2 x;
             if constexpr (NF == 2) x = load.post(id, l, v[it], v2[it]);
             else x = load.post(id, l, v[it]);
-            if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true>(l, wl)] = x;
+            if ((L * W) % T == 0 || e < L * W) tile[lds_slot<true, !BIG>(l, wl)] = x;
         }
         __syncthreads();
-        stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+        stage_lds<L, R0, L, true, RG, !BIG, BIG>(tile, tw, w, rg);
     } else {
-        __syncthreads();   // tw[] complete
+        if constexpr (!BIG) __syncthreads();   // tw[] complete
         id.i = i0 + (w < wvalid ? w : 0);   // same LineId as the fetch: index work is shared (masked below)
 #pragma unroll
         for (int it = 0; it < nit0; ++it) {
@@ -717,8 +759,15 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
                     else x[q] = load.post(id, b + q * m0, x[q]);
                 }
                 dft_p<R0>(x);
+                if constexpr (BIG) {
+                    float2 pw[R0];
+                    twiddle_powers<R0>(tw[b], pw);
 #pragma unroll
-                for (int q = 1; q < R0; ++q) x[dft_slot<R0>(q)] = cmul(x[dft_slot<R0>(q)], tw[q * b]);
+                    for (int q = 1; q < R0; ++q) x[dft_slot<R0>(q)] = cmul(x[dft_slot<R0>(q)], pw[q]);
+                } else {
+#pragma unroll
+                    for (int q = 1; q < R0; ++q) x[dft_slot<R0>(q)] = cmul(x[dft_slot<R0>(q)], tw[q * b]);
+                }
 #pragma unroll
                 for (int q = 0; q < R0; ++q) tile[lds_slot<false>(b + q * m0, w)] = x[dft_slot<R0>(q)];
             }
@@ -726,11 +775,11 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
     }
     __syncthreads();
     if constexpr (S >= 3) {
-        stage_lds<L, R1, L / R0, ROWS, RG>(tile, tw, w, rg);
+        stage_lds<L, R1, L / R0, ROWS, RG, !BIG, BIG>(tile, tw, w, rg);
         __syncthreads();
     }
     if constexpr (S >= 4) {
-        stage_lds<L, R2, L / (R0 * R1), ROWS, RG>(tile, tw, w, rg);
+        stage_lds<L, R2, L / (R0 * R1), ROWS, RG, !BIG, BIG>(tile, tw, w, rg);
         __syncthreads();
     }
 
@@ -750,7 +799,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d
         if ((rowsL % RG == 0) || g < rowsL) {
             float2 x[RL];
 #pragma unroll
-            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<ROWS>(g * RL + q, w)];
+            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<ROWS, !BIG>(g * RL + q, w)];
             dft_p<RL>(x);
             const int kb = kbase(g);
             float2 Tw = make_float2(1.f, 0.f);
@@ -1395,7 +1444,7 @@ struct StoreRowWindow {
 #define RCFM_FFT_TWO_STAGE 1
 #endif
 #define RCFM_FFT_LONG_TABLE3(X) X(480, 10, 8, 6, 1) X(500, 10, 10, 5, 1)
-#if RCFM_FFT_TWO_STAGE
+#if RCFM_FFT_TWO_STAGE && !defined(RCFM_FFT_LONG3)
 #define RCFM_FFT_LONG_TABLE(X) X(480, 24, 20, 1, 1) X(500, 25, 20, 1, 1)
 #else
 #define RCFM_FFT_LONG_TABLE(X) RCFM_FFT_LONG_TABLE3(X)
@@ -1465,7 +1514,7 @@ struct StoreRowWindow {
 #define RCFM_FFT_600_THREADS 1024
 #endif
 constexpr int tile_threads(int L) {
-    return L == 600 ? RCFM_FFT_600_THREADS : L > kFftMaxL ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256;
+    return L == 600 ? RCFM_FFT_600_THREADS : (L > kFftMaxL || big_tile_pair(L)) ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256;
 }
 
 // Big tiles are instantiated for the plain functors only (the streaming passes of long transforms).
