@@ -75,6 +75,12 @@ def path_bytes(N, C, B, A, kind):
     return 16.0 * N + C * (16.0 * B + per_ch)
 
 
+def path_read_bytes(N, C, B, A, kind):
+    """Read-only algorithmic bytes per buffer (the north star says "HBM-read roofline")."""
+    per_ch = {"FM": 8 * B + 4 * A, "MFM": 8 * B + 8 * A, "WBFM": 28 * B + 16 * A}[kind]
+    return 8.0 * N + C * (8.0 * B + per_ch)
+
+
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,12 +99,40 @@ def read_profile(lib):
     return out
 
 
-def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan):
-    """The oracle (a numpy port of the reference's CPU path), one thread, on a bounded
-    sample: one Tuner.load of the full buffer + `nchan` channels of Tuner.run + demod,
-    extrapolated as t_load + C * mean(t_channel).  Test infrastructure used as a
-    reported baseline only."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+_CPU = {}
+
+
+def _cpu_channel(i):
+    """One channel of the reference's caller loop (multi_fm_server.py:100-106) on the oracle: worker body of the
+    parallel CPU baseline (the tuner and its spectrum arrive through fork, copy-on-write)."""
+    oracle, tuner, kind, B, A = _CPU["oracle"], _CPU["tuner"], _CPU["kind"], _CPU["B"], _CPU["A"]
+    demod = getattr(oracle, kind)(B, A)
+    t0 = time.perf_counter()
+    out = demod.run(tuner.run(int(i)))        # reference-faithful O(N) roll + full-length window
+    return int(i), time.perf_counter() - t0, out
+
+
+def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan, workers):
+    """The oracle (a numpy port of the reference's CPU path) timed on this box's host cores, on a bounded
+    sample: one Tuner.load of the full buffer + `nchan` channels of Tuner.run + demod.
+      single: one process, one thread, sequential channels like multi_fm_server.py:98-106;
+              t = t_load + C * mean(t_channel);
+      fair:   the per-channel part fanned out over `workers` processes (each rolls and windows the whole
+              N-point spectrum per channel like the reference does, so the worker count is bounded by host
+              memory, not by the core count); t = t_load + C / (channels per second with `workers` busy).
+    Test infrastructure used as a reported baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multiprocessing as mp
     import radiocore_oracle as oracle
     tuner = oracle.Tuner()
     for f in centres:
@@ -109,21 +143,114 @@ def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan):
     t_load = time.perf_counter() - t0
     # the spectral window is built once and cached by the reference (tuner.py:155-157): not timed
     tuner._win = oracle.shifted_window("hann", N)
-    t_ch = []
-    outputs = {}
-    for i in np.linspace(0, C - 1, nchan).astype(int):
-        demod = getattr(oracle, kind)(B, A)
-        t0 = time.perf_counter()
-        iq = tuner.run(int(i))            # reference-faithful O(N) roll + window
-        outputs[int(i)] = demod.run(iq)
-        t_ch.append(time.perf_counter() - t0)
-    t_total = t_load + C * float(np.mean(t_ch))
-    return outputs, {
-        "value": N / t_total / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+    _CPU.update(oracle=oracle, tuner=tuner, kind=kind, B=B, A=A)
+    sample = [int(i) for i in np.linspace(0, C - 1, nchan).astype(int)]
+    outputs, t_ch = {}, []
+    for i in sample:
+        _, dt, out = _cpu_channel(i)
+        outputs[i] = out
+        t_ch.append(dt)
+    t_single = t_load + C * float(np.mean(t_ch))
+    info = {
+        "value": N / t_single / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "cpu": cpu_model(), "logical_cores": os.cpu_count(),
         "sample": "oracle Tuner.load on the full %d-sample buffer (%.1f s) + %d of %d channels of "
-                  "Tuner.run+%s.run (mean %.2f s each), extrapolated t_load + C*t_channel = %.0f s per buffer; "
-                  "host has %d logical cores" % (N, t_load, nchan, C, kind, float(np.mean(t_ch)), t_total,
-                                                 os.cpu_count()),
+                  "Tuner.run+%s.run (mean %.2f s each), extrapolated t_load + C*t_channel = %.0f s per buffer"
+                  % (N, t_load, nchan, C, kind, float(np.mean(t_ch)), t_single),
+    }
+    if workers > 1:
+        try:
+            per_worker = 2
+            todo = [sample[j % len(sample)] for j in range(workers * per_worker)]
+            with mp.get_context("fork").Pool(workers) as pool:
+                t0 = time.perf_counter()
+                pool.map(_cpu_channel, todo, chunksize=1)
+                wall = time.perf_counter() - t0
+            rate = len(todo) / wall
+            t_fair = t_load + C / rate
+            info["fair"] = {
+                "value": N / t_fair / 1e6, "unit": "Msamples/s", "cores": workers,
+                "sample": "same load + %d channel runs on %d worker processes in %.1f s (%.2f channels/s), "
+                          "extrapolated t_load + C/rate = %.0f s per buffer" % (len(todo), workers, wall, rate, t_fair),
+            }
+        except Exception as e:   # a baseline, never a reason to lose the bench line
+            info["fair"] = {"value": None, "error": repr(e)[:200]}
+    _CPU.clear()
+    return outputs, info
+
+
+def measure_config(name, lib, hip, steps, warmup, chunk=0):
+    """One extra configuration on this GPU (cfg3 / cfg5; cfg4 is the headline): K timed steps of
+    rcfm_tuner_load + rcfm_pipeline_run, input resident in HBM, same accounting as the headline."""
+    N, C, B, A, raster, kind = CONFIGS[name]
+    ch = 2 if kind == "WBFM" else 1
+    x, centres, f_in = synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
+    rolls = (ctypes.c_int64 * C)(*[int(f_in - f) for f in centres])
+    bws = (ctypes.c_int32 * C)(*([B] * C))
+    tuner, demod = ctypes.c_void_p(), ctypes.c_void_p()
+    hip.check(lib.rcfm_tuner_create(N, C, rolls, bws, ctypes.byref(tuner)))
+    hip.check(lib.rcfm_tuner_shard(tuner, 0, C))
+    hip.check(lib.rcfm_demod_create({"FM": 0, "MFM": 1, "WBFM": 2}[kind], C, B, A, 75e-6, chunk, ctypes.byref(demod)))
+    audio = torch.empty((C, A, ch), dtype=torch.float32, device="cuda")
+
+    def step():
+        hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), hip.stream()))
+        hip.check(lib.rcfm_pipeline_run(tuner, demod, 0, C, hip.ptr(audio), hip.stream()))
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    finite = bool(torch.isfinite(audio).all())
+    hip.check(lib.rcfm_demod_destroy(demod))
+    hip.check(lib.rcfm_tuner_destroy(tuner))
+    del x, audio
+    torch.cuda.empty_cache()
+    alg = path_bytes(N, C, B, A, kind)
+    return {
+        "workload": "%s: %d-channel Tuner at %d MSPS -> %d x %s (%d -> %d Hz)" % (name, C, N // 1_000_000, C, kind, B, A),
+        "ms_per_step": round(dt * 1e3, 4), "value": round(N / dt / 1e6, 1), "unit": "Msamples/s", "steps": steps,
+        "path_algorithmic_GB": round(alg / 1e9, 3), "path_hbm_frac": round(alg / dt / HBM_PEAK, 4),
+        "path_hbm_frac_read": round(path_read_bytes(N, C, B, A, kind) / dt / HBM_PEAK, 4),
+        "output_finite": finite, "parity": "tests/test_hip_configs.py::test_%s_full_size_%s" % (name, kind.lower()),
+    }
+
+
+def measure_batched_cfg2(lib, hip, steps, warmup, T=1024):
+    """BASELINE configs[1] (one 240 kSPS WBFM channel) is 13.4 MB of algorithmic traffic: latency-bound as one
+    call.  Its bandwidth is measured SURVEY.md section 8d's way: T consecutive buffers as T channels of one
+    rcfm_demod_run (the demodulator's `batch`)."""
+    B, A = 240_000, 48_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ph = torch.cumsum(torch.randn(T, B, generator=g, device="cuda") * 0.3, dim=1)
+    iq = torch.polar(torch.ones_like(ph), ph).to(torch.complex64).contiguous()
+    del ph
+    demod = ctypes.c_void_p()
+    hip.check(lib.rcfm_demod_create(2, T, B, A, 75e-6, 0, ctypes.byref(demod)))
+    audio = torch.empty((T, A, 2), dtype=torch.float32, device="cuda")
+
+    def step():
+        hip.check(lib.rcfm_demod_run(demod, 0, T, hip.ptr(iq), hip.ptr(audio), hip.stream()))
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    hip.check(lib.rcfm_demod_destroy(demod))
+    alg = T * (48.0 * B + 40.0 * A)
+    return {
+        "workload": "cfg2 batched: %d one-second 240 kSPS buffers as %d channels of one WBFM.run (no tuner)" % (T, T),
+        "ms_per_step": round(dt * 1e3, 4), "value": round(T * B / dt / 1e6, 1), "unit": "Msamples/s", "steps": steps,
+        "path_algorithmic_GB": round(alg / 1e9, 3), "path_hbm_frac": round(alg / dt / HBM_PEAK, 4),
+        "parity": "tests/test_hip_parity.py::test_batched_demod_matches_oracle, test_golden_wbfm",
     }
 
 
@@ -134,7 +261,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--chunk", type=int, default=0, help="channels per pass (0 = library default)")
-    ap.add_argument("--cpu-channels", type=int, default=3, help="channels in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-channels", type=int, default=8, help="channels in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=8,
+                    help="worker processes of the parallel ('fair') CPU baseline (each holds ~8 GB while it rolls "
+                         "and windows the 240M-point spectrum; 0 or 1 = skip)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other GPU configurations (cfg3, cfg5, batched cfg2) reported beside the headline")
     ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-fed path: page-locked host buffer, H2D of buffer i+1 on a copy "
@@ -249,15 +381,18 @@ def main():
     alg_bytes = stage_bytes(dominant, N, B, A, kind) * units
     achieved = alg_bytes / per_launch_s if per_launch_s else 0.0
     total_alg = 16.0 * N + mine * (path_bytes(N, C, B, A, kind) - 16.0 * N) / C
+    total_read = 8.0 * N + mine * (path_read_bytes(N, C, B, A, kind) - 8.0 * N) / C
 
     # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (FETCH_SIZE x its
     # gfx950 correction + WRITE_SIZE, collected separately; profiles/r01_e_pmc_hbm_traffic.txt)
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
             entry = json.load(fh).get(dominant)
-        if entry and args.config == "cfg4":
+        # the committed PMC passes describe cfg4 with the default chunking on one GPU: nothing else is claimed
+        if entry and args.config == "cfg4" and world == 1 and args.chunk == 0:
             traffic = float(entry["hbm_bytes_per_launch"])
+            traffic_source = entry.get("source")
     except (OSError, ValueError, KeyError):
         traffic = None
 
@@ -282,68 +417,74 @@ def main():
             if world > 1 else "single GPU",
         },
         "path_hbm_frac": round(total_alg / (ms_per_step * 1e-3) / HBM_PEAK, 4),
+        "path_hbm_frac_read": round(total_read / (ms_per_step * 1e-3) / HBM_PEAK, 4),
         "path_algorithmic_GB": round(total_alg / 1e9, 3),
+        "path_algorithmic_read_GB": round(total_read / 1e9, 3),
         "roofline": {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
             "launch_us": round(per_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": alg_bytes,
             "share_of_step": round(dom[1] / args.steps / ms_per_step, 3),
         },
     }
 
+    if world > 1:
+        # Channel sharding scales the per-channel stages; the replicated wideband FFT does not.
+        # Per-channel-stage rate of this run = channel samples through (step time - this rank's FFT time), and the
+        # Amdahl bound of the end-to-end speed-up at this world size from the single-GPU shares.
+        fft_ms = prof_all["tuner_fft_N"][1]
+        chan_ms = max(ms_per_step - fft_ms, 1e-6)
+        result["channel_stage_value"] = {
+            "value": round(C * B / (chan_ms * 1e-3) / 1e6, 1), "unit": "channel Msamples/s",
+            "note": "all %d channels' samples / (step time - the replicated wideband FFT, %.3f ms on rank 0)" % (C, fft_ms)}
+        alg_fft, alg_all = 16.0 * N, path_bytes(N, C, B, A, kind)
+        result["amdahl_bound_speedup"] = round(alg_all / (alg_fft + (alg_all - alg_fft) / world), 3)
+
     if args.pcie and world == 1:
-        # Host-fed variant: the wideband buffer starts in page-locked host memory
-        # (radiocore.tools.Buffer(cuda=True)); two device buffers; the copy of buffer i+1 runs on its own
-        # stream while buffer i is processed.  Steady state is bound by max(copy, compute).
-        from radiocore.tools import Buffer
+        # Host-fed variant through the package's ingest component: the wideband buffer
+        # starts in page-locked host memory (radiocore.tools.Buffer(cuda=True)); radiocore.tools.Feeder keeps two
+        # device slots and copies buffer i+1 on its own stream while buffer i is processed.  Steady state is
+        # bound by max(copy, compute).
+        from radiocore.tools import Buffer, Feeder
         host = Buffer(N, dtype=np.complex64, cuda=True)
         host.data[:] = x.cpu().numpy()
-        src = torch.from_numpy(host.data)
-        dev = [torch.empty_like(x), torch.empty_like(x)]
-        copy_stream = torch.cuda.Stream()
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        done = [torch.cuda.Event(), torch.cuda.Event()]
+        feeder = Feeder(N, dtype=np.complex64, depth=2)
 
-        def feed(i):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(done[i % 2])          # the kernels that read this buffer are finished
-                dev[i % 2].copy_(src, non_blocking=True)
-                ready[i % 2].record(copy_stream)
+        def consume():
+            with feeder.next() as xd:
+                hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(xd), hip.stream()))
+                hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), hip.stream()))
 
-        def consume(i):
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ready[i % 2])
-            hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(dev[i % 2]), hip.stream()))
-            hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), hip.stream()))
-            done[i % 2].record(cur)
-
-        for e in done:
-            e.record(torch.cuda.current_stream())
-        feed(0)
-        consume(0)
+        feeder.submit(host.data)
+        consume()
         torch.cuda.synchronize()
         k = max(args.steps, 4)
         t0 = time.perf_counter()
-        feed(0)
+        feeder.submit(host.data)
         for i in range(k):
             if i + 1 < k:
-                feed(i + 1)
-            consume(i)
+                feeder.submit(host.data)
+            consume()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / k
         result["pcie_inclusive"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(N / dt / 1e6, 1),
                                     "unit": "Msamples/s", "h2d_GBps": None,
-                                    "note": "page-locked host buffer, H2D of buffer i+1 overlapped with buffer i"}
+                                    "note": "radiocore.tools.Feeder: page-locked host buffer, H2D of buffer i+1 "
+                                            "overlapped with the kernels of buffer i"}
         t0 = time.perf_counter()
-        dev[0].copy_(src, non_blocking=True)
+        feeder.submit(host.data)
+        with feeder.next():
+            pass
         torch.cuda.synchronize()
         result["pcie_inclusive"]["h2d_GBps"] = round(N * 8 / (time.perf_counter() - t0) / 1e9, 1)
+        del feeder, host
 
     if rank == 0 and world == 1 and args.cpu_channels > 0:
         x_host = x.cpu().numpy()
         ref_audio, result["cpu_baseline"] = cpu_baseline(x_host, f_in, centres, N, C, B, A, kind,
-                                                         args.cpu_channels)
+                                                         args.cpu_channels, args.cpu_workers)
+        del x_host
         # full-size parity spot check (outside the timed region): first-buffer state on
         # both sides, the oracle's sampled channels against the GPU's
         hip.check(lib.rcfm_demod_reset_state(demod, hip.stream()))
@@ -358,10 +499,19 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
-    if rank == 0:
-        print(json.dumps(result))
     hip.check(lib.rcfm_demod_destroy(demod))
     hip.check(lib.rcfm_tuner_destroy(tuner))
+    if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras:
+        # the other GPU configurations of BASELINE.json on the same box, outside the headline's timed region
+        del x, audios, audio
+        torch.cuda.empty_cache()
+        result["other_configs"] = {
+            "cfg3": measure_config("cfg3", lib, hip, 50, 5),
+            "cfg5": measure_config("cfg5", lib, hip, 20, 3),
+            "cfg2_batched": measure_batched_cfg2(lib, hip, 10, 2),
+        }
+    if rank == 0:
+        print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 

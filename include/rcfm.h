@@ -53,6 +53,7 @@ typedef enum rcfm_demod_kind {
 typedef struct rcfm_tuner_s* rcfm_tuner_t;
 typedef struct rcfm_demod_s* rcfm_demod_t;
 typedef struct rcfm_resampler_s* rcfm_resampler_t;
+typedef struct rcfm_feeder_s* rcfm_feeder_t;
 
 /* ---- library / device ---------------------------------------------------- */
 
@@ -121,6 +122,26 @@ int rcfm_demod_destroy(rcfm_demod_t d);
  * channels [first, first+count), chunk by chunk.  audio: [count][A][ch]. */
 int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void* audio,
                       void* stream);
+
+/* ---- host ingest (the step before Tuner.load) -------------------------------- */
+
+/* The reference hands its DSP thread a buffer in mapped / shared memory (cusignal.get_shared_mem at
+ * radiocore/tools/buffer.py:43 and ringbuffer.py:51; consumer loop examples/multi_fm_server.py:95-98).  Here the
+ * host side is page-locked memory and the wideband buffer crosses PCIe once: a feeder owns `depth` device slots of
+ * `bytes` each, a copy stream and one event pair per slot, so the copy of buffer i+1 runs under the kernels of
+ * buffer i.  device_slots = NULL: the library allocates the slots; otherwise `depth` caller-owned device pointers.
+ *   submit(src_host)      queue the H2D copy of the next buffer (page-locked source: rcfm_host_register, or any
+ *                         pinned allocation) into the next free slot; RCFM_ERR_STATE when all slots are in flight
+ *   acquire(stream, &p)   make `stream` wait for the oldest submitted copy; p = its device slot (pass it to
+ *                         rcfm_tuner_load on the same stream)
+ *   release(stream)       the work queued on `stream` so far is the last reader of that slot                */
+int rcfm_host_register(void* host, size_t bytes);
+int rcfm_host_unregister(void* host);
+int rcfm_feeder_create(size_t bytes, int depth, void* const* device_slots, rcfm_feeder_t* out);
+int rcfm_feeder_submit(rcfm_feeder_t f, const void* src_host);
+int rcfm_feeder_acquire(rcfm_feeder_t f, void* stream, void** dptr);
+int rcfm_feeder_release(rcfm_feeder_t f, void* stream);
+int rcfm_feeder_destroy(rcfm_feeder_t f);
 
 /* ---- primitives (class parity with radiocore/analog) ---------------------- */
 

@@ -730,6 +730,26 @@ struct rcfm_resampler_s {
     DeviceBuffer spec_in, spec_out, work;
 };
 
+
+// Overlapped host -> device ingest (rcfm_feeder_*): `depth` device slots, one copy stream, an event pair per slot.
+struct rcfm_feeder_s {
+    size_t bytes = 0;
+    int depth = 0;
+    bool owns = false;
+    std::vector<void*> slot;
+    std::vector<hipEvent_t> ready, done;   // ready: the copy into the slot has landed; done: its consumer has finished
+    hipStream_t copy = nullptr;
+    uint64_t head = 0, tail = 0;           // submitted / released buffers
+    ~rcfm_feeder_s() {
+        if (copy) (void)hipStreamSynchronize(copy);
+        for (auto e : ready) (void)hipEventDestroy(e);
+        for (auto e : done) (void)hipEventDestroy(e);
+        if (owns)
+            for (auto p : slot) (void)hipFree(p);
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // extern "C"
 // ---------------------------------------------------------------------------
@@ -1004,6 +1024,79 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                          as_stream(stream));
         }
     });
+}
+
+// ---- host ingest -----------------------------------------------------------------
+
+int rcfm_host_register(void* host, size_t bytes) {
+    return guarded([&] {
+        RC_REQUIRE(host != nullptr && bytes > 0, RCFM_ERR_ARG, "bad host range");
+        RC_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    });
+}
+
+int rcfm_host_unregister(void* host) {
+    return guarded([&] { RC_HIP(hipHostUnregister(host)); });
+}
+
+int rcfm_feeder_create(size_t bytes, int depth, void* const* device_slots, rcfm_feeder_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out != nullptr && bytes > 0 && depth >= 1 && depth <= 16, RCFM_ERR_ARG, "bad feeder geometry");
+        auto f = std::make_unique<rcfm_feeder_s>();
+        f->bytes = bytes;
+        f->depth = depth;
+        f->owns = device_slots == nullptr;
+        RC_HIP(hipStreamCreateWithFlags(&f->copy, hipStreamNonBlocking));
+        for (int i = 0; i < depth; ++i) {
+            void* p = device_slots ? device_slots[i] : nullptr;
+            if (!device_slots) RC_HIP(hipMalloc(&p, bytes));
+            RC_REQUIRE(p != nullptr, RCFM_ERR_ARG, "NULL device slot");
+            f->slot.push_back(p);
+            hipEvent_t a, b;
+            RC_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            f->ready.push_back(a);
+            RC_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            f->done.push_back(b);
+        }
+        *out = f.release();
+    });
+}
+
+int rcfm_feeder_submit(rcfm_feeder_t f, const void* src_host) {
+    return guarded([&] {
+        RC_REQUIRE(f && src_host, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(f->head - f->tail < (uint64_t)f->depth, RCFM_ERR_STATE,
+                   "every feeder slot is in flight: release one before submitting another buffer");
+        const int i = (int)(f->head % (uint64_t)f->depth);
+        RC_HIP(hipStreamWaitEvent(f->copy, f->done[i], 0));   // the kernels that read this slot last time are finished
+        RC_HIP(hipMemcpyAsync(f->slot[i], src_host, f->bytes, hipMemcpyHostToDevice, f->copy));
+        RC_HIP(hipEventRecord(f->ready[i], f->copy));
+        f->head += 1;
+    });
+}
+
+int rcfm_feeder_acquire(rcfm_feeder_t f, void* stream, void** dptr) {
+    return guarded([&] {
+        RC_REQUIRE(f && dptr, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(f->tail < f->head, RCFM_ERR_STATE, "rcfm_feeder_acquire without a submitted buffer");
+        const int i = (int)(f->tail % (uint64_t)f->depth);
+        RC_HIP(hipStreamWaitEvent(as_stream(stream), f->ready[i], 0));
+        *dptr = f->slot[i];
+    });
+}
+
+int rcfm_feeder_release(rcfm_feeder_t f, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(f, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(f->tail < f->head, RCFM_ERR_STATE, "rcfm_feeder_release without an acquired buffer");
+        const int i = (int)(f->tail % (uint64_t)f->depth);
+        RC_HIP(hipEventRecord(f->done[i], as_stream(stream)));
+        f->tail += 1;
+    });
+}
+
+int rcfm_feeder_destroy(rcfm_feeder_t f) {
+    return guarded([&] { delete f; });
 }
 
 // ---- primitives --------------------------------------------------------------

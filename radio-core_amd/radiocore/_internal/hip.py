@@ -51,6 +51,13 @@ SIGNATURES = {
     "rcfm_demod_get_taps": [_vp, _fp, _fp],
     "rcfm_demod_destroy": [_vp],
     "rcfm_pipeline_run": [_vp, _vp, _i, _i, _vp, _vp],
+    "rcfm_host_register": [_vp, _sz],
+    "rcfm_host_unregister": [_vp],
+    "rcfm_feeder_create": [_sz, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp)],
+    "rcfm_feeder_submit": [_vp, _vp],
+    "rcfm_feeder_acquire": [_vp, _vp, ctypes.POINTER(_vp)],
+    "rcfm_feeder_release": [_vp, _vp],
+    "rcfm_feeder_destroy": [_vp],
     "rcfm_resampler_create": [_i, _i, _i, _i, ctypes.POINTER(_vp)],
     "rcfm_resampler_run": [_vp, _vp, _vp, _vp],
     "rcfm_resampler_destroy": [_vp],

@@ -7,3 +7,4 @@ from radiocore.tools.carrousel import *
 from radiocore.tools.ringbuffer import *
 from radiocore.tools.sharding import *
 from radiocore.tools.wire import *
+from radiocore.tools.feeder import *

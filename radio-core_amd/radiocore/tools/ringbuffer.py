@@ -25,6 +25,7 @@ class RingBuffer:
         self._head = 0          # next write position
         self._tail = 0          # next read position
         self._count = 0
+        self._epoch = 0         # bumped by every reset: transfers that straddle one are forgotten
         self._cv = threading.Condition()
         self._buffer, self._owner = _hostmem.zeros(self._capacity, dtype, self._cuda)
 
@@ -48,6 +49,7 @@ class RingBuffer:
     def reset(self):
         with self._cv:
             self._head = self._tail = self._count = 0
+            self._epoch += 1
 
     def __str__(self):
         return str(self._buffer)
@@ -58,6 +60,9 @@ class RingBuffer:
         return first, size - first
 
     def put(self, buffer):
+        """Copies `buffer` in.  The lock only guards the indices: the copy itself runs outside it (single
+        producer / single consumer: the regions being written and read are disjoint), so a consumer copying a
+        long buffer out never stalls the producer callback, like the reference's lock-free ring."""
         size = len(buffer)
         if size > self._capacity:
             raise ValueError("Input buffer is bigger than ring capacity.")
@@ -68,14 +73,18 @@ class RingBuffer:
                 if self._print_overflow:
                     print("overflow")
                 self._head = self._tail = self._count = 0
-            a, b = self._split(self._head, size)
-            if a:
-                self._buffer[self._head:self._head + a] = buffer[:a]
-            if b:
-                self._buffer[:b] = buffer[a:size]
-            self._head = (self._head + size) % self._capacity
-            self._count += size
-            self._cv.notify_all()
+                self._epoch += 1
+            head, epoch = self._head, self._epoch
+        a, b = self._split(head, size)
+        if a:
+            self._buffer[head:head + a] = buffer[:a]
+        if b:
+            self._buffer[:b] = buffer[a:size]
+        with self._cv:
+            if epoch == self._epoch:            # (a concurrent reset() forgets this transfer)
+                self._head = (head + size) % self._capacity
+                self._count += size             # published after the copy
+                self._cv.notify_all()
 
     def get(self, buffer, timeout=3.0):
         size = len(buffer)
@@ -84,11 +93,14 @@ class RingBuffer:
         with self._cv:
             if not self._cv.wait_for(lambda: self._count >= size, timeout):
                 return None
-            a, b = self._split(self._tail, size)
-            if a:
-                buffer[:a] = self._buffer[self._tail:self._tail + a]
-            if b:
-                buffer[a:size] = self._buffer[:b]
-            self._tail = (self._tail + size) % self._capacity
-            self._count -= size
+            tail, epoch = self._tail, self._epoch
+        a, b = self._split(tail, size)
+        if a:
+            buffer[:a] = self._buffer[tail:tail + a]
+        if b:
+            buffer[a:size] = self._buffer[:b]
+        with self._cv:
+            if epoch == self._epoch:            # an overflow reset in between already dropped these samples
+                self._tail = (tail + size) % self._capacity
+                self._count -= size
         return True

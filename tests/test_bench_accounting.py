@@ -38,3 +38,13 @@ def test_channel_grids_fit_the_wideband_buffer():
         span = (C - 1) * raster + B
         pad = (-span) % (C * B // C)                  # tuner.py:170: span padded to a multiple of the mean bandwidth
         assert span + pad <= N, name
+
+
+def test_read_only_bytes_match_the_survey_totals():
+    """SURVEY.md section 8d, read-only column (the north star says "HBM-read roofline")."""
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg4"]
+    assert abs(bench.path_read_bytes(N, C, B, A, kind) - 11.55e9) < 0.01e9
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg5"]
+    assert abs(bench.path_read_bytes(N, C, B, A, kind) - 2.70e9) < 0.01e9
+    N, C, B, A, _raster, kind = bench.CONFIGS["cfg3"]
+    assert abs(bench.path_read_bytes(N, C, B, A, kind) - 350e6) < 1e6

@@ -298,3 +298,50 @@ def test_pinned_buffer_feeds_the_tuner(rc):
     ring.put(x)
     out = np.zeros(N, np.complex64)
     assert ring.get(out) is True and np.array_equal(out, x)
+
+
+def test_feeder_overlaps_copies_and_matches_synchronous_load(rc):
+    """SURVEY.md section 8f-1, second half: radiocore.tools.Feeder (rcfm_feeder_*) copies buffer i+1 from
+    page-locked memory on its own stream while buffer i is processed; every buffer must come out exactly as
+    with the synchronous Tuner.load (reference hand-over: examples/multi_fm_server.py:95-98)."""
+    N, B, A, K = 600000, 60000, 12000, 5
+    centres = [100e6, 100.1e6, 99.9e6]
+    base = workloads.wideband(N, 100e6, centres, B, gain=0.5)
+    hosts = []
+    for k in range(K):                       # K distinct page-locked buffers
+        buf = rc.Buffer(N, dtype=np.complex64, cuda=True)
+        buf.data[:] = np.roll(base, 1000 * k) * np.float32(1.0 - 0.1 * k)
+        hosts.append(buf)
+
+    def tuner():
+        t = rc.Tuner()
+        for f in centres:
+            t.add_channel(f, B, rc.MFM(B, A))
+        t.request_bandwidth(float(N))
+        return t
+
+    sync, fed = tuner(), tuner()
+    want = []
+    for buf in hosts:
+        sync.load(buf.data)
+        want.append((sync.run(1), sync.run_all()))
+    feeder = rc.Feeder(N, dtype=np.complex64, depth=2)
+    assert feeder.depth == 2
+    feeder.submit(hosts[0].data)
+    got = []
+    for k in range(K):
+        if k + 1 < K:
+            feeder.submit(hosts[k + 1].data)          # in flight while buffer k is processed
+        with feeder.next() as x:
+            fed.load(x)
+            got.append((fed.run(1), fed.run_all()))
+    for k in range(K):
+        assert np.array_equal(got[k][0], want[k][0]), k
+        assert np.array_equal(got[k][1], want[k][1]), k
+    # protocol errors are reported, not ignored
+    feeder.submit(hosts[0].data)
+    feeder.submit(hosts[1].data)
+    with pytest.raises(RuntimeError, match="in flight"):
+        feeder.submit(hosts[2].data)
+    with pytest.raises(ValueError, match="size"):
+        feeder.submit(np.zeros(10, np.complex64))
