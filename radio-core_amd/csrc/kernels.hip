@@ -582,7 +582,10 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
     }
 #pragma unroll
     for (int it = 0; it < NL; ++it) {                              // unconditional, clamped 16-byte loads
-        const int64_t e = t0 - HP + 4 * (int64_t)(tid + kThreads * it);   // total % 4 == 0: whole quads are in or out
+        // the last sweep is ragged: its surplus threads re-read the tile's last quad (an L1 hit) -- reading on
+        // into the next tile's samples made this kernel fetch 1.5x its input (profiles/r02_c_hbm_traffic.md)
+        const int q = (tid + kThreads * it < NV) ? tid + kThreads * it : NV - 1;
+        const int64_t e = t0 - HP + 4 * (int64_t)q;                 // total % 4 == 0: whole quads are in or out
         v[it] = *reinterpret_cast<const float4*>(xc + (e < 0 ? 0 : (e > total - 4 ? total - 4 : e)));
     }
 #pragma unroll
