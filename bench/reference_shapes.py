@@ -2,7 +2,8 @@
 """The reference's own timing harness shapes (tests/benchmark.py:81-110) on the HIP backend.
 
 Same objects, sizes and call pattern as the reference script -- FM/MFM/WBFM 256 000 -> 32 000,
-complex Decimate 10 000 000 / 2 500 000 -> 250 000, Tuner 10 000 000 with 3 x 250 000-Hz channels
+complex Decimate 10 000 000 / 2 500 000 -> 250 000 (host arrays like the reference, and device-resident;
+RCFM_FFT=rocfft gives the rocFFT-backed path for comparison), Tuner 10 000 000 with 3 x 250 000-Hz channels
 (load + run(0)), 50 timeit iterations, host numpy arrays in and out (so each call pays its PCIe
 copies, exactly like the reference's cuda=True numbers would) -- but on non-zero synthetic input:
 the reference feeds zeros, which makes WBFM compute 0/0 (pll.py:58).  Prints seconds per call.
@@ -49,6 +50,13 @@ def main():
         dec = Decimate(n, 250000)
         print("#### Decimate benchmark (input %d, output 250000, HIP)" % n)
         score("Decimate", lambda: dec.run(z))
+        zd = torch.from_numpy(z).cuda()
+        decd = Decimate(n, 250000, cuda=True)
+
+        def dec_resident():
+            decd.run(zd)
+            torch.cuda.synchronize()
+        score("Decimate (device in/out)", dec_resident)
     print("=" * 80)
     N = 10_000_000
     tuner = Tuner()

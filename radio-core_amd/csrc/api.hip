@@ -728,6 +728,13 @@ struct rcfm_resampler_s {
     ResampleGeom geom;
     std::unique_ptr<FftPlan> fwd, inv;
     DeviceBuffer spec_in, spec_out, work;
+    // complex down-sampling on the FFT engine: forward transform, then the Tuner's fused gather + window +
+    // inverse transform with roll = 0 and the Hamming weight (the same math, decimate.py:47-48 vs tuner.py:159-161)
+    std::unique_ptr<FftEngine> eng_n, eng_m;
+    DeviceBuffer tmp_n, tmp_m, zero_roll;
+    // only bins |k| <= m/2 of the long spectrum are read: its last pass stores just the rows that hold them
+    bool windowed = false;
+    FftRowWindow window{0, 0};
 };
 
 
@@ -1111,6 +1118,25 @@ int rcfm_resampler_create(int C, int n, int m, int is_complex, rcfm_resampler_t*
         r->m = m;
         r->cplx = is_complex != 0;
         r->geom.build(n, m, 0.54, r->cplx);
+        FftPlanDesc probe;
+        if (r->cplx && use_engine() && m <= n && fft_plan_describe(n, &probe) && fft_plan_describe(m, &probe)) {
+            r->eng_n = std::make_unique<FftEngine>(n);
+            r->eng_m = std::make_unique<FftEngine>(m);
+            r->spec_in.reset((size_t)C * n * sizeof(float2));
+            r->tmp_n.reset((size_t)C * r->eng_n->tmp_stride() * sizeof(float2));
+            r->tmp_m.reset((size_t)C * r->eng_m->tmp_stride() * sizeof(float2));
+            std::vector<int64_t> zeros((size_t)C, 0);
+            r->zero_roll.upload(zeros.data(), zeros.size() * sizeof(int64_t));
+            const int64_t n1 = r->eng_n->row_length(), rows = n / n1;
+            const int64_t hi = (r->geom.nyq + 1) / n1;                        // last row of the positive bins
+            const int64_t lo = (n - r->geom.nneg - 2) / n1;                   // first row of the negative bins
+            if (C == 1 && lo > hi + 1 && lo < rows) {                         // (rows are counted per signal)
+                r->windowed = true;
+                r->window = FftRowWindow{(int)lo, (int)hi};
+            }
+            *out = r.release();
+            return;
+        }
         if (r->cplx) {
             r->fwd = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, (size_t)C, false);
             r->inv = std::make_unique<FftPlan>(FftKind::C2C_INVERSE, (size_t)m, (size_t)C, true);
@@ -1131,6 +1157,14 @@ int rcfm_resampler_run(rcfm_resampler_t r, const void* in, void* out, void* stre
         RC_REQUIRE(r && in && out, RCFM_ERR_ARG, "NULL argument");
         hipStream_t s = as_stream(stream);
         const ResampleGeom& g = r->geom;
+        if (r->eng_n) {
+            r->eng_n->c2c(static_cast<const float2*>(in), r->spec_in.as<float2>(), r->tmp_n.as<float2>(), r->C, false,
+                          1.0f, s, r->windowed ? &r->window : nullptr);
+            TunerGather tg{r->spec_in.as<float2>(), r->n, r->zero_roll.as<int64_t>(), 0.54, g.nyq, g.nneg, g.nyq_mode,
+                           nullptr, 0, r->n};
+            fused_tuner_ifft(*r->eng_m, tg, static_cast<float2*>(out), r->tmp_m.as<float2>(), r->C, s);
+            return;
+        }
         if (r->cplx) {
             r->fwd->exec(const_cast<void*>(in), r->spec_in.get(), r->work.get(), s);
             launch_spectrum_c2c(r->spec_in.as<float2>(), r->n, r->n, nullptr, static_cast<float2*>(out), r->m,
@@ -1150,6 +1184,26 @@ int rcfm_resampler_destroy(rcfm_resampler_t r) {
     return guarded([&] { delete r; });
 }
 
+extern "C++" {
+namespace {
+// Device copies of filter taps, keyed by their values: Bandpass / Deemphasis hand the same host array to every call
+// (bandpass.py:72, deemphasis.py:64), so after the first call nothing is allocated, uploaded or waited for.
+const float* cached_taps(const std::vector<float>& taps) {
+    static std::mutex mu;
+    static std::map<std::vector<float>, std::unique_ptr<DeviceBuffer>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(taps);
+    if (it == cache.end()) {
+        if (cache.size() >= 64) cache.clear();   // (buffers of launches still in flight are freed stream-ordered by hipFree)
+        auto buf = std::make_unique<DeviceBuffer>();
+        buf->upload(taps.data(), taps.size() * sizeof(float));
+        it = cache.emplace(taps, std::move(buf)).first;
+    }
+    return it->second->as<float>();
+}
+}  // namespace
+}  // extern "C++"
+
 int rcfm_filtfilt(int C, int n, const float* taps_host, int ntaps, const void* x, void* y, void* stream) {
     return guarded([&] {
         RC_REQUIRE(taps_host && x && y, RCFM_ERR_ARG, "NULL argument");
@@ -1158,12 +1212,9 @@ int rcfm_filtfilt(int C, int n, const float* taps_host, int ntaps, const void* x
                    "The length of the input vector x must be greater than padlen, which is " +
                        std::to_string(3 * ntaps) + ".");
         hipStream_t s = as_stream(stream);
-        auto g = zero_phase_kernel(taps_host, ntaps);
-        DeviceBuffer gd;
-        gd.upload(g.data(), g.size() * sizeof(float));
-        launch_pilot_stage(nullptr, static_cast<const float*>(x), nullptr, static_cast<float*>(y), n, C,
-                           gd.as<float>(), ntaps - 1, 0.f, s);
-        RC_HIP(hipStreamSynchronize(s));   // gd is released on return
+        const float* gd = cached_taps(zero_phase_kernel(taps_host, ntaps));
+        launch_pilot_stage(nullptr, static_cast<const float*>(x), nullptr, static_cast<float*>(y), n, C, gd,
+                           ntaps - 1, 0.f, s);
     });
 }
 
@@ -1173,29 +1224,62 @@ int rcfm_lfilter_fir(int C, int n, const float* taps_host, int ntaps, void* stat
         RC_REQUIRE(taps_host && x && y && (state || ntaps < 2), RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(C >= 1 && n >= 1 && ntaps >= 1, RCFM_ERR_ARG, "bad lfilter size");
         hipStream_t s = as_stream(stream);
-        DeviceBuffer td;
-        td.upload(taps_host, (size_t)ntaps * sizeof(float));
-        launch_fir(static_cast<const float*>(x), static_cast<float*>(y), n, 1, C, td.as<float>(), ntaps,
+        const float* td = cached_taps(std::vector<float>(taps_host, taps_host + ntaps));
+        launch_fir(static_cast<const float*>(x), static_cast<float*>(y), n, 1, C, td, ntaps,
                    static_cast<const float*>(state), nullptr, s);
-        launch_fir_state(static_cast<const float*>(x), n, 1, C, td.as<float>(), ntaps,
-                         static_cast<float*>(state), s);
-        RC_HIP(hipStreamSynchronize(s));
+        launch_fir_state(static_cast<const float*>(x), n, 1, C, td, ntaps, static_cast<float*>(state), s);
     });
 }
+
+extern "C++" {
+namespace {
+// Plans and workspaces of rcfm_hilbert, keyed by (n, C): PLL.step (pll.py:25-34) is called once per buffer with the
+// same geometry, so nothing is planned, allocated or synchronised after the first call.
+struct HilbertPlan {
+    std::unique_ptr<FftEngine> eng;            // engine lengths: real -> full spectrum -> masked inverse transform
+    std::unique_ptr<FftPlan> fwd, inv;         // otherwise rocFFT (r2c, mask kernel, c2c inverse)
+    DeviceBuffer spec, tmp, work;
+};
+HilbertPlan& hilbert_plan(int n, int C) {
+    static std::map<std::pair<int, int>, std::unique_ptr<HilbertPlan>> plans;
+    auto it = plans.find({n, C});
+    if (it == plans.end()) {
+        auto p = std::make_unique<HilbertPlan>();
+        FftPlanDesc probe;
+        if (use_engine() && fft_plan_describe(n, &probe)) {
+            p->eng = std::make_unique<FftEngine>(n);
+            p->spec.reset((size_t)C * n * sizeof(float2));
+            p->tmp.reset((size_t)C * p->eng->tmp_stride() * sizeof(float2));
+        } else {
+            p->fwd = std::make_unique<FftPlan>(FftKind::R2C, (size_t)n, (size_t)C, false);
+            p->inv = std::make_unique<FftPlan>(FftKind::C2C_INVERSE, (size_t)n, (size_t)C, true);
+            p->spec.reset((size_t)C * (n / 2 + 1) * sizeof(float2));
+            p->work.reserve(std::max(p->fwd->work_bytes(), p->inv->work_bytes()));
+        }
+        it = plans.emplace(std::make_pair(n, C), std::move(p)).first;
+    }
+    return *it->second;
+}
+std::mutex g_hilbert_mu;
+}  // namespace
+}  // extern "C++"
 
 int rcfm_hilbert(int C, int n, const void* x, void* z, void* stream) {
     return guarded([&] {
         RC_REQUIRE(x && z, RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(C >= 1 && n >= 1, RCFM_ERR_ARG, "bad hilbert size");
         hipStream_t s = as_stream(stream);
-        FftPlan fwd(FftKind::R2C, (size_t)n, (size_t)C, false);
-        FftPlan inv(FftKind::C2C_INVERSE, (size_t)n, (size_t)C, true);
-        DeviceBuffer P((size_t)C * (n / 2 + 1) * sizeof(float2));
-        DeviceBuffer work(std::max(fwd.work_bytes(), inv.work_bytes()));
-        fwd.exec(const_cast<void*>(x), P.get(), work.get(), s);
-        launch_hilbert_mask(P.as<float2>(), static_cast<float2*>(z), n, C, 1.0f / (float)n, s);
-        inv.exec(z, z, work.get(), s);
-        RC_HIP(hipStreamSynchronize(s));
+        std::lock_guard<std::mutex> lock(g_hilbert_mu);
+        HilbertPlan& p = hilbert_plan(n, C);
+        if (p.eng) {
+            fused_real_fft(*p.eng, static_cast<const float*>(x), p.spec.as<float2>(), p.tmp.as<float2>(), C,
+                           kKeepLowerHalf /* bins above n/2 are never read */, s);
+            fused_hilbert_ifft(*p.eng, p.spec.as<float2>(), static_cast<float2*>(z), p.tmp.as<float2>(), C, s);
+            return;
+        }
+        p.fwd->exec(const_cast<void*>(x), p.spec.get(), p.work.get(), s);
+        launch_hilbert_mask(p.spec.as<float2>(), static_cast<float2*>(z), n, C, 1.0f / (float)n, s);
+        p.inv->exec(z, z, p.work.get(), s);
     });
 }
 

@@ -20,6 +20,9 @@ struct TunerGather {
     // (N - roll[c]) mod N, so source bin d (|d| <= halo) of channel c is X[base32[c] + d].
     const int32_t* base32 = nullptr;
     int64_t halo = 0;
+    // Distance between the spectra of consecutive signals (general path only): 0 = every channel reads the one
+    // wideband spectrum (the Tuner); n = one spectrum per signal (complex Decimate, decimate.py:47-48).
+    int64_t x_batch = 0;
 };
 // theta != nullptr: instead of out, angle(ifft) / pi goes to theta [count][B] float32 -- all an FM
 // discriminator needs (fm.py:60-65), and half the bytes.
@@ -36,6 +39,9 @@ void fused_real_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, 
 // signal u = (m + lmr) + j (m - lmr) as the store of the last pass.  U and u may alias.
 void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m, float2* u, float2* tmp,
                             int count, hipStream_t s);
+
+// scipy.signal.hilbert (pll.py:34): z = ifft(h U) / n for full spectra U [count][n] of real signals; U and z may alias.
+void fused_hilbert_ifft(const FftEngine& e, const float2* U, float2* z, float2* tmp, int count, hipStream_t s);
 
 // The same two stages for real signals transformed two at a time: U2 [ceil(count/2)][n] =
 // FFT(x[2c] + j x[2c+1]); the Hilbert load of channel c unpacks its own spectrum from U2.

@@ -67,6 +67,7 @@ struct LoadTunerGatherT {
     float a0;
     int B, nyq, nneg, nyq_mode;
     int line_stride;   // in_l of the pass: k = l * line_stride + i
+    int64_t x_batch;   // spectrum of signal c starts at X + c * x_batch (0: one shared spectrum)
 
     // Signed offset d of the source bin of output bin k (source = d mod N); ok = false: zero fill.
     // Branch-free per lane; only the nyq_mode tests (kernel arguments) branch, uniformly.
@@ -105,7 +106,7 @@ struct LoadTunerGatherT {
     __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t, unsigned) const {
         bool ok;
         const int d = source_offset(l * line_stride + (int)id.i, ok);   // the same expression as in post()
-        return X[rolled(d, (I)roll[id.batch])];
+        return (X + (int64_t)id.batch * x_batch)[rolled(d, (I)roll[id.batch])];
     }
     __device__ __forceinline__ float2 post(const LineId& id, int l, float2 v) const {
         const int k = l * line_stride + (int)id.i;
@@ -117,7 +118,7 @@ struct LoadTunerGatherT {
         float2 y = make_float2(v.x * w, v.y * w);
         if (nyq_mode == NYQ_DOWN) {   // Y[+N/2] += X[-N/2]: one element per channel
             // workgroup-uniform address and value (hoisted out of the per-element code); lanes select
-            const float2 x2 = X[rolled(-half, (I)roll[id.batch])];
+            const float2 x2 = (X + (int64_t)id.batch * x_batch)[rolled(-half, (I)roll[id.batch])];
             const float w2 = (k == half) ? window(-half) : 0.f;
             y.x += x2.x * w2;
             y.y += x2.y * w2;
@@ -495,10 +496,11 @@ void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, flo
         ld.nneg = g.nneg;
         ld.nyq_mode = g.nyq_mode;
         ld.line_stride = (int)e.desc().pass[0].in_l;
+        ld.x_batch = g.x_batch;
         fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), count, ld, st0, s);
     };
     const bool series = 6.28318530717958647692 * ((double)(B / 2 + 2) / (double)g.N) < 0.059;
-    if (series && g.base32 && g.halo >= B / 2 + 1 && g.nyq_mode != NYQ_UP && B <= g.N) {
+    if (series && g.base32 && g.halo >= B / 2 + 1 && g.nyq_mode != NYQ_UP && B <= g.N && g.x_batch == 0) {
         LoadTunerGatherFast ld;
         const double a1 = 1.0 - g.a0;
         ld.X = g.X;
@@ -557,6 +559,18 @@ void fused_hilbert_ifft_mix(const FftEngine& e, const float2* U, const float* m,
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
+void fused_hilbert_ifft(const FftEngine& e, const float2* U, float2* z, float2* tmp, int count, hipStream_t s) {
+    if (count <= 0) return;
+    const int64_t n = e.desc().n;
+    const int np = e.npass();
+    LoadHilbertMask ld{U, (int)n, e.desc().pass[0].in_l};
+    fftk::StorePlainT<false> st0{tmp, 1.0f};
+    fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, n, e.tmp_stride()), count, ld, st0, s);
+    middle_passes(e, 1, np - 2, tmp, count, s);
+    fftk::LoadPlainT<false> ldl{tmp};
+    fftk::StorePlainT<true> stl{z, (float)(1.0 / (double)n)};
+    fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
+}
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
                          hipStream_t s, bool from_phase) {
     if (count <= 0) return;
