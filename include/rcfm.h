@@ -54,6 +54,7 @@ typedef struct rcfm_tuner_s* rcfm_tuner_t;
 typedef struct rcfm_demod_s* rcfm_demod_t;
 typedef struct rcfm_resampler_s* rcfm_resampler_t;
 typedef struct rcfm_feeder_s* rcfm_feeder_t;
+typedef struct rcfm_comm_s* rcfm_comm_t;
 
 /* ---- library / device ---------------------------------------------------- */
 
@@ -142,6 +143,24 @@ int rcfm_feeder_submit(rcfm_feeder_t f, const void* src_host);
 int rcfm_feeder_acquire(rcfm_feeder_t f, void* stream, void** dptr);
 int rcfm_feeder_release(rcfm_feeder_t f, void* stream);
 int rcfm_feeder_destroy(rcfm_feeder_t f);
+
+/* ---- multi-GPU: the audio gather (the publish step, examples/multi_fm_server.py:103-106) ---------- */
+
+/* One process per GPU; channels shard by contiguous index range (radiocore/tools/sharding.py) and the only
+ * collective of the path brings every rank's [C/G][A][ch] float32 block to the publishing rank over xGMI.  RCCL is
+ * opened at run time by the first of these calls (a single-GPU process never loads it).
+ *   unique_id(id)                 rank 0 creates the 128-byte rendezvous token; the host distributes it to the other
+ *                                 ranks by whatever control channel it has (file, socket, MPI, torch.distributed store)
+ *   comm_init_rank(G, r, id, &c)  collective: every rank calls it once, with its GPU current (hipSetDevice)
+ *   gather_audio(c, root, send, floats, recv, stream)
+ *                                 `floats` float32 values from every rank land at recv + rank * floats on `root`
+ *                                 (recv may be NULL elsewhere), asynchronously on `stream`: rank blocks are equal,
+ *                                 pad the shorter ones when C is not divisible by G (sharding.gather_audio does).  */
+#define RCFM_UNIQUE_ID_BYTES 128
+int rcfm_comm_unique_id(void* id128_host);
+int rcfm_comm_init_rank(int world, int rank, const void* id128_host, rcfm_comm_t* out);
+int rcfm_gather_audio(rcfm_comm_t c, int root, const void* send, size_t floats_per_rank, void* recv, void* stream);
+int rcfm_comm_destroy(rcfm_comm_t c);
 
 /* ---- primitives (class parity with radiocore/analog) ---------------------- */
 

@@ -10,6 +10,9 @@
 #include <tuple>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is opened on the first rcfm_comm_* call (dlopen), never linked
+
 #include "common.h"
 #include "fft_engine.h"
 #include "fft_plan.h"
@@ -738,6 +741,50 @@ struct rcfm_resampler_s {
 };
 
 
+// RCCL, bound at run time: a process that never gathers (one GPU, or a host that gathers with its own transport)
+// does not load it; a process that already loaded an RCCL (PyTorch's ProcessGroupNCCL) gets that same copy.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.Gather = reinterpret_cast<decltype(r.Gather)>(dlsym(r.lib, "ncclGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    });
+    RC_REQUIRE(r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Gather, RCFM_ERR_RUNTIME,
+               "RCCL (librccl.so) is not available in this process");
+    return r;
+}
+
+#define RC_NCCL(expr)                                                                              \
+    do {                                                                                           \
+        ncclResult_t rc_n_ = (expr);                                                               \
+        if (rc_n_ != ncclSuccess)                                                                  \
+            throw ::rcfm::Error{RCFM_ERR_RUNTIME, std::string(#expr) + ": " +                      \
+                                                      (rccl().GetErrorString ? rccl().GetErrorString(rc_n_) : "RCCL error")}; \
+    } while (0)
+
+struct rcfm_comm_s {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+};
+
 // Overlapped host -> device ingest (rcfm_feeder_*): `depth` device slots, one copy stream, an event pair per slot.
 struct rcfm_feeder_s {
     size_t bytes = 0;
@@ -1104,6 +1151,47 @@ int rcfm_feeder_release(rcfm_feeder_t f, void* stream) {
 
 int rcfm_feeder_destroy(rcfm_feeder_t f) {
     return guarded([&] { delete f; });
+}
+
+// ---- multi-GPU: the audio gather ------------------------------------------------------
+
+int rcfm_comm_unique_id(void* id128_host) {
+    return guarded([&] {
+        RC_REQUIRE(id128_host != nullptr, RCFM_ERR_ARG, "NULL argument");
+        static_assert(sizeof(ncclUniqueId) == RCFM_UNIQUE_ID_BYTES, "RCCL unique id size changed");
+        ncclUniqueId id;
+        RC_NCCL(rccl().GetUniqueId(&id));
+        std::memcpy(id128_host, &id, sizeof(id));
+    });
+}
+
+int rcfm_comm_init_rank(int world, int rank, const void* id128_host, rcfm_comm_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out && id128_host && world >= 1 && rank >= 0 && rank < world, RCFM_ERR_ARG, "bad communicator geometry");
+        auto c = std::make_unique<rcfm_comm_s>();
+        c->world = world;
+        c->rank = rank;
+        ncclUniqueId id;
+        std::memcpy(&id, id128_host, sizeof(id));
+        RC_NCCL(rccl().CommInitRank(&c->comm, world, id, rank));
+        *out = c.release();
+    });
+}
+
+int rcfm_gather_audio(rcfm_comm_t c, int root, const void* send, size_t floats_per_rank, void* recv, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(c && send, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(root >= 0 && root < c->world, RCFM_ERR_INDEX, "root rank outside the communicator");
+        RC_REQUIRE(c->rank != root || recv != nullptr, RCFM_ERR_ARG, "the root rank needs a receive buffer");
+        RC_NCCL(rccl().Gather(send, recv, floats_per_rank, ncclFloat32, root, c->comm, as_stream(stream)));
+    });
+}
+
+int rcfm_comm_destroy(rcfm_comm_t c) {
+    return guarded([&] {
+        if (c && c->comm) (void)rccl().CommDestroy(c->comm);
+        delete c;
+    });
 }
 
 // ---- primitives --------------------------------------------------------------

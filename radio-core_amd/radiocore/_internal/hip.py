@@ -58,6 +58,10 @@ SIGNATURES = {
     "rcfm_feeder_acquire": [_vp, _vp, ctypes.POINTER(_vp)],
     "rcfm_feeder_release": [_vp, _vp],
     "rcfm_feeder_destroy": [_vp],
+    "rcfm_comm_unique_id": [_vp],
+    "rcfm_comm_init_rank": [_i, _i, _vp, ctypes.POINTER(_vp)],
+    "rcfm_gather_audio": [_vp, _i, _vp, _sz, _vp, _vp],
+    "rcfm_comm_destroy": [_vp],
     "rcfm_resampler_create": [_i, _i, _i, _i, ctypes.POINTER(_vp)],
     "rcfm_resampler_run": [_vp, _vp, _vp, _vp],
     "rcfm_resampler_destroy": [_vp],

@@ -199,3 +199,20 @@ def tuner_odd_cases(impl, g):
     tuner.load(x)
     return [("odd ch0", rel_err(_asnp(tuner.run(0)), g["iq_ch0"])),
             ("odd ch1", rel_err(_asnp(tuner.run(1)), g["iq_ch1"]))]
+
+
+FM_OFFSETS = (5000, 50000)
+
+
+def fm_offcentre_cases(impl, g):
+    """Stations 5 kHz and 50 kHz off the channel centre (tests/golden/make_golden_offcentre.py): per offset the
+    error of impl.FM against the reference's own output and against the float64 evaluation of the same
+    mathematics, and the reference's own error against that truth.  Returns {offset: (vs_ref, vs_truth, ref_vs_truth)}."""
+    out = {}
+    for off in FM_OFFSETS:
+        x = workloads.single_channel(240000, i=1, offset=off)
+        g.check_input("in_%d" % off, x)
+        y = _asnp(impl.FM(240000, 48000).run(x))[:, 0]
+        ref, truth = g["ref_%d" % off], g["truth_%d" % off]
+        out[off] = (rel_err(y, ref), rel_err(y, truth), rel_err(ref, truth))
+    return out

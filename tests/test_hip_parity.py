@@ -57,6 +57,19 @@ def test_golden_fm(rc, golden):
     _check(gc.fm_cases(rc, golden("fm")))
 
 
+def test_fm_off_centre_carrier_follows_the_mathematics(rc, golden):
+    """Known, documented divergence: the reference unwraps the phase in float32 (fm.py:62), so
+    with a carrier 5 / 50 kHz off the channel centre ITS output is 2.8e-4 / 2.2e-3 away from the float64 evaluation
+    of fm.py:60-67.  The HIP discriminator takes wrapped phase steps and has no accumulated phase: it must sit
+    within 1e-5 of the float64 truth, and its distance from the reference must be the reference's own error."""
+    res = gc.fm_offcentre_cases(rc, golden("fm_offcentre"))
+    print(res)
+    for off, (vs_ref, vs_truth, ref_vs_truth) in res.items():
+        assert vs_truth <= 0.1 * TOL, (off, vs_truth)
+        assert ref_vs_truth > TOL
+        assert abs(vs_ref - ref_vs_truth) <= 0.05 * ref_vs_truth, (off, vs_ref, ref_vs_truth)
+
+
 def test_golden_mfm(rc, golden):
     _check(gc.mfm_cases(rc, golden("mfm")))
 

@@ -108,3 +108,28 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, kind, C, exact):
         else:
             for c in range(C):
                 assert rel_err(got[b][c], want[c]) <= 0.05 * TOL, (kind, b, c)
+
+
+def test_c_abi_gather_world_of_one():
+    """rcfm_comm_* / rcfm_gather_audio (RCCL bound at run time): the degenerate one-rank communicator on this
+    GPU -- unique id, init, a gather that must reproduce the block, destroy.  (RCCL refuses two ranks on one
+    device, so N > 1 of this entry point runs only on a multi-GPU node; the N > 1 protocol of the path is
+    covered above with torch.distributed.)"""
+    import ctypes
+    _paths()
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    hip.torch()
+    token = (ctypes.c_char * 128)()
+    hip.check(lib.rcfm_comm_unique_id(ctypes.cast(token, ctypes.c_void_p)))
+    comm = ctypes.c_void_p()
+    hip.check(lib.rcfm_comm_init_rank(1, 0, ctypes.cast(token, ctypes.c_void_p), ctypes.byref(comm)))
+    block = torch.randn(3, 4800, 2, device="cuda")
+    out = torch.zeros_like(block)
+    hip.check(lib.rcfm_gather_audio(comm, 0, hip.ptr(block), block.numel(), hip.ptr(out), hip.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, block)
+    with pytest.raises(IndexError):
+        hip.check(lib.rcfm_gather_audio(comm, 1, hip.ptr(block), block.numel(), hip.ptr(out), hip.stream()))
+    hip.check(lib.rcfm_comm_destroy(comm))

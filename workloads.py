@@ -34,25 +34,27 @@ def station_mpx(i, B, stereo=True):
             + 0.3 * (L - R) * np.sin(2 * np.pi * 38000 * t))
 
 
-def station_iq(i, B, deviation=None, stereo=True, noise=0.0):
+def station_iq(i, B, deviation=None, stereo=True, noise=0.0, offset=0):
     """Complex baseband FM signal of station i, complex128 [B].
 
     deviation defaults to 75 kHz scaled by B / 240 kHz so that reduced-size test
     channels keep the per-sample phase step well inside (-pi, pi).
+    offset (integer Hz): carrier offset from the channel centre -- the accumulated phase then grows to
+    2 pi offset over the buffer, which is where the reference's float32 unwrap (fm.py:62) loses precision.
     """
     if deviation is None:
         deviation = 75e3 * B / 240000.0
     mpx = station_mpx(i, B, stereo)
-    s = np.exp(2j * np.pi * deviation * np.cumsum(mpx) / B)
+    s = np.exp(2j * np.pi * (deviation * np.cumsum(mpx) + int(offset) * np.arange(B, dtype=np.float64)) / B)
     if noise:
         rng = np.random.default_rng(5000 + i)
         s = s + noise * (rng.standard_normal(B) + 1j * rng.standard_normal(B))
     return s
 
 
-def single_channel(B, i=0, deviation=None, stereo=True, noise=0.01):
+def single_channel(B, i=0, deviation=None, stereo=True, noise=0.01, offset=0):
     """One station at baseband as complex64 [B] (configs 1 and 2)."""
-    return station_iq(i, B, deviation, stereo, noise).astype(np.complex64)
+    return station_iq(i, B, deviation, stereo, noise, offset).astype(np.complex64)
 
 
 def channel_grid(C, raster, f0=100e6):
