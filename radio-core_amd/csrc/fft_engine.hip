@@ -70,7 +70,7 @@ bool smooth235(int64_t n) {
 
 // Split n into `np` factors <= kFftMaxL, each >= 16, as balanced as possible, preferring
 // factorizations whose tiled dimensions (n_1 and m_1..m_{p-1}) are multiples of 16.
-bool split(int64_t n, int np, int max_l, int64_t* f) {
+bool split(int64_t n, int np, int max_l, int64_t* f, double* best_cost = nullptr) {
     std::vector<int64_t> divs;
     for (int64_t d = 16; d <= max_l; ++d)
         if (n % d == 0) divs.push_back(d);
@@ -88,8 +88,15 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
                 mn = std::min(mn, cur[i]);
             }
             double cost = (double)mx / (double)mn;
-            for (int i = 0; i < np; ++i)
+            for (int i = 0; i < np; ++i) {
                 if (!is_fast_length(cur[i])) cost += 3.0;   // no compile-time specialised kernel
+                // residency of the tile: up to ~426 points three (or more) workgroups share a CU, the big tiles run
+                // as two 1024-thread workgroups, 427..512 points as two 512-thread ones -- the slowest of the three
+                // per byte (N = 1e8: 400 x 625 x 400 runs 8 % faster than 400 x 500 x 500)
+                if (cur[i] > kFftMaxL) cost += 0.15;
+                else if (cur[i] > 426) cost += 0.35;
+            }
+            cost += 0.02 * (double)cur[0] / (double)mn;     // the first pass has the longest stride: keep it short
             // tail tiles waste lanes: penalise tiled extents that are not multiples of 16
             auto tail = [](int64_t extent) {
                 const int64_t tiles = (extent + 15) / 16;
@@ -112,6 +119,7 @@ bool split(int64_t n, int np, int max_l, int64_t* f) {
                 best = cost;
                 ok = true;
                 for (int i = 0; i < np; ++i) f[i] = cur[i];
+                if (best_cost) *best_cost = cost;
             }
             return;
         }
@@ -163,8 +171,18 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
                     break;
                 }
             }
-            if (split(n, cand, max_l, f)) {
+            double c_reg = 0.0;
+            if (split(n, cand, max_l, f, &c_reg)) {
                 np = cand;
+                // three passes: a big tile among them may beat the best all-regular split
+                int64_t fb[kFftMaxPasses];
+                double c_big = 0.0;
+                if (cand == 3 && default_cap && big_tiles_enabled() && split(n, 3, kFftBigL, fb, &c_big) && c_big < c_reg) {
+                    bool all_fast = true;
+                    for (int i = 0; i < 3; ++i) all_fast = all_fast && is_fast_length(fb[i]);
+                    if (all_fast)
+                        for (int i = 0; i < 3; ++i) f[i] = fb[i];
+                }
                 break;
             }
         }

@@ -22,9 +22,13 @@ def test_lengths_of_the_hot_path_are_planned():
             for s in range(p.nstages):
                 assert p.radix[s] in (2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 24, 25, 32)   # 20..32: in-register composites
                 r *= p.radix[s]
-            # 512 = two workgroups per CU; up to 640 (one workgroup per CU) only where that saves a pass
-            assert r == p.L and 16 <= p.L <= (640 if n == 240_000_000 else 512)
+            # up to 512 points in ordinary tiles; the big tiles (600 / 625 / 640 points, two 1024-thread workgroups per
+            # CU) only in three-pass plans: where they save a fourth pass (2.4e8) or beat two 500-point passes (1e8)
+            assert r == p.L and 16 <= p.L <= (640 if plan.npass == 3 else 512)
         assert prod == n
+    assert [fft_model.describe(100_000_000).passes[t].L for t in range(3)] == [400, 625, 400]
+    assert [fft_model.describe(240_000_000).passes[t].L for t in range(3)] == [600, 625, 640]
+    assert [fft_model.describe(240_000).passes[t].L for t in range(2)] == [480, 500]
 
 
 @pytest.mark.parametrize("n", [100, 24001, 7 * 4096, 255])
