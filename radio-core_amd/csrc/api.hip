@@ -427,6 +427,8 @@ struct rcfm_demod_s {
                 if (pd.npass == 2 && A < B && A % (2 * n1) == 0 && fft_plan_describe(A, &pa, 0, fa, 2)) {
                     eng_Ad = std::make_unique<FftEngine>(A, fa, 2);
                     buf_TA.reserve(c * eng_Ad->tmp_stride() * sizeof(float2));
+                    if (const int pitch = audio_pitch())   // padded rows of the packed audio
+                        buf_V.reserve(c * (size_t)(A / eng_Ad->row_length()) * pitch * sizeof(float2));
                 }
             }
             if (kind != RCFM_WBFM) {
@@ -445,18 +447,34 @@ struct rcfm_demod_s {
     }
 
     // mfm.py:63-65 / wbfm.py:90-100: de-emphasis (per-leg state), joint DC removal, clip.
-    void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s, bool have_dc = false) {
+    // Can run_deemph take its input in padded rows (fused_fft_decim_ifft's out_pitch)?  Only the fused kernel does.
+    bool deemph_fused() const { return ((int64_t)A * ch) % 4 == 0 && A >= 50; }
+    // Row pitch (samples) of the packed audio between IFFT_A's last pass and the de-emphasis kernel: rows of n_1
+    // samples padded to whole 128-byte lines; 0 = contiguous.
+    int audio_pitch() const {
+        static const bool off = [] {
+            const char* e = std::getenv("RCFM_AUDIO_PITCH");   // =0: contiguous rows (A/B runs)
+            return e && e[0] == '0';
+        }();
+        if (off || !eng_Ad || kind != RCFM_WBFM || !deemph_fused()) return 0;
+        const int64_t n1 = eng_Ad->row_length();
+        return (n1 % 16 == 0 || (n1 * 2) % 4 != 0) ? 0 : (int)((n1 + 15) / 16 * 16);
+    }
+
+    void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s, bool have_dc = false,
+                    int row = 0, int pitch = 0) {
         const bool fast = ((int64_t)A * ch) % 4 == 0;
         if (fast && have_dc && A >= 50) {
             // de-emphasis, DC removal and clip in one kernel: the mean comes from the DC bin (buf_dc)
             {
                 StageTimer tm(ST_DEEMPH, s);
-                launch_fir51(v, audio, A, ch, cnt, taps_h, st, nullptr, buf_dc.as<float2>(), s);
+                launch_fir51(v, audio, A, ch, cnt, taps_h, st, nullptr, buf_dc.as<float2>(), s, row, pitch);
             }
             StageTimer tm(ST_DEEMPH_STATE, s);
-            launch_fir_state(v, A, ch, cnt, taps.as<float>(), 51, st, s);
+            launch_fir_state(v, A, ch, cnt, taps.as<float>(), 51, st, s, row, pitch);
             return;
         }
+        RC_REQUIRE(pitch == 0, RCFM_ERR_RUNTIME, "padded audio rows need the fused de-emphasis kernel");
         {
             StageTimer tm(ST_DEEMPH, s);
             if (fast)
@@ -546,13 +564,15 @@ struct rcfm_demod_s {
                     return e && e[0] == '0';
                 }();
                 if (paired && eng_Ad && !no_decim && fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, cnt)) {
+                    const int pitch = audio_pitch();
                     {   // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
                         StageTimer tm(ST_FFT_B, s);
                         fused_fft_decim_ifft(*eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
-                                             buf_dc.as<float2>(), s);
+                                             buf_dc.as<float2>(), s, pitch);
                     }
                     float* st = state.as<float>() + (size_t)first * ch * 50;
-                    run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true);
+                    run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true,
+                               pitch ? (int)eng_Ad->row_length() : 0, pitch);
                     return;
                 }
                 if (paired) {

@@ -88,8 +88,11 @@ void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out
 // decimate.py:48) and the first pass of IFFT_A (plan ea = (L2, n_1)) on one tile (k_fft_tile2_decim), then
 // ea's last pass.  out [count][A] = l + j r (= float32 [count][A][2]); dc as below.
 bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int count);
+// out_pitch > 0: sample k_1 + n_1 k_2 of a signal goes to out[k_2 out_pitch + k_1] (n_1 = ea's first pass length; a signal
+// then occupies (A / n_1) out_pitch values): with n_1 = 100 the 16-sample store segments of the last pass start every
+// 800 bytes and straddle 128-byte lines; at a pitch of 112 they are aligned, and the de-emphasis kernel skips the pad.
 void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float2* out, float2* tmp_a,
-                          int count, const float* wr, float scale, float2* dc, hipStream_t s);
+                          int count, const float* wr, float scale, float2* dc, hipStream_t s, int out_pitch = 0);
 
 // The same decimation for PAIRS of real channels (FM / MFM, fm.py:66): tmp_f holds the first pass of the
 // pair FFT (fused_real_pair_fft_first: x real signals, or their phases with the discriminator on the load);

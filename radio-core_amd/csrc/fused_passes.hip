@@ -722,7 +722,7 @@ bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int 
 }
 
 void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float2* out, float2* tmp_a,
-                          int count, const float* wr, float scale, float2* dc, hipStream_t s) {
+                          int count, const float* wr, float scale, float2* dc, hipStream_t s, int out_pitch) {
     if (count <= 0) return;
     const int64_t B = ef.desc().n, A = ea.desc().n;
     fftk::LoadPlainT<false> ld{tmp_f};
@@ -733,7 +733,13 @@ void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2
                RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
     fftk::LoadPlainT<false> ldl{tmp_a};
     fftk::StorePlainT<true> stl{out, 1.0f};
-    fftk::launch_fft_pass<kRowsOnly>(ea.pass_dev(1, ea.tmp_stride(), A), count, ldl, stl, s);
+    FftPassDev last = ea.pass_dev(1, ea.tmp_stride(), A);
+    if (out_pitch > 0) {   // rows of n_1 samples at a pitch of whole 128-byte lines: aligned 16-sample segments
+        RC_REQUIRE(out_pitch >= last.p.out_k && last.p.n_o1 * last.p.n_o2 == 1, RCFM_ERR_RUNTIME, "bad audio row pitch");
+        last.out_batch = (A / last.p.out_k) * (int64_t)out_pitch;
+        last.p.out_k = out_pitch;
+    }
+    fftk::launch_fft_pass<kRowsOnly>(last, count, ldl, stl, s);
 }
 
 // Last pass of an inverse transform that carried two real signals: real part -> channel 2P, imaginary

@@ -84,11 +84,15 @@ void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const fl
 int fir51_tiles(int64_t n, int ch);
 // dc != nullptr ([batch], from launch_stereo_unpack / launch_spectrum_real_full): the kernel also
 // removes the mean and clips (mfm.py:64-65, wbfm.py:97-100); `partial` is then unused.  Needs n >= 50.
+// row_samples / row_pitch_samples (fir51 and fir_state): the input signal is stored in rows of row_samples samples at a
+// pitch of row_pitch_samples (0 = contiguous): the padded output of fused_fft_decim_ifft.
 void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const float* taps_host,
-                  const float* state, float* partial, const float2* dc, hipStream_t stream);
+                  const float* state, float* partial, const float2* dc, hipStream_t stream, int row_samples = 0,
+                  int row_pitch_samples = 0);
 // Advance `state` to the end of the buffer (must run after launch_fir on the stream).
 void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
-                      float* state, hipStream_t stream);
+                      float* state, hipStream_t stream, int row_samples = 0,
+                      int row_pitch_samples = 0);
 // mfm.py:64-65 / wbfm.py:97-100: y -= mean(y) over the channel's n*ch samples; clip +-0.999.
 // partial: [batch][nparts] partial sums of y.
 void launch_dc_clip(float* y, int64_t n, int ch, int batch, const float* partial, int nparts,

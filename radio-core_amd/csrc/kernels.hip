@@ -544,6 +544,17 @@ struct DeemphTaps {
     float b[51];
 };
 
+// Where interleaved input value e of a signal lives: plain (row_len = 0), or in rows of row_len values at a pitch of
+// row_pitch (the inverse FFT's last pass writes 16-sample segments at a stride of n_1 samples; padding that stride to
+// whole 128-byte lines keeps its stores aligned -- n_1 = 100 -> 112 -- and the reader skips the pad).
+struct RowLayout {
+    int row_len, row_pitch;
+    int64_t signal_stride;     // values between consecutive signals
+    __device__ __forceinline__ int64_t at(int64_t e) const {
+        return row_len ? e + (e / row_len) * (int64_t)(row_pitch - row_len) : e;
+    }
+};
+
 constexpr int kFirPer = 8;
 constexpr int kFirFastTile = kThreads * kFirPer;   // 2048 interleaved outputs per workgroup
 
@@ -557,27 +568,26 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
                                                     int64_t total, DeemphTaps taps,
                                                     const float* __restrict__ state,
                                                     float* __restrict__ partial,
-                                                    const float2* __restrict__ dc) {
+                                                    const float2* __restrict__ dc, RowLayout lay) {
     constexpr int T = kFirFastTile, PER = kFirPer, HIST = 50 * CH;
     constexpr int HP = (HIST + 3) / 4 * 4;                          // history rounded to whole 16-byte loads
-    constexpr int NW = (PER + HP) / 4;                              // float4 window reads per thread
     constexpr int NV = (T + HP) / 4;                                // float4 loads per workgroup
-    // z[t0 - HP + e] lives at xpos(e): 8 values, 4 pad dwords -- the window reads (thread tid starts at
-    // e = 8 tid) are ds_read_b128 at a lane stride of 12 dwords instead of 8: no bank conflicts beyond the
-    // 4 cycles 64 lanes x 16 bytes need anyway.
-    auto xpos = [](int e) -> int { return (e >> 3) * 12 + (e & 7); };
-    __shared__ __attribute__((aligned(16))) float x_s[((T + HP + 7) / 8) * 12];
+    // z[t0 - HP + e] lives at xpos(e): 8 values, 2 pad dwords -- the window reads (thread tid starts at
+    // e = 8 tid) are ds_read_b64 / b32 at a lane stride of 10 dwords instead of 8: the 64 lanes spread evenly
+    // over the banks (at 8 they were 8-way conflicts, as in the pilot stage).
+    auto xpos = [](int e) -> int { return (e >> 3) * 10 + (e & 7); };
+    __shared__ __attribute__((aligned(16))) float x_s[((T + HP + 7) / 8) * 10];
     __shared__ float red[kThreads / 64];
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * T;
-    const float* xc = x + (int64_t)c * total;
+    const float* xc = x + (int64_t)c * lay.signal_stride;
     float* yc = y + (int64_t)c * total;
     constexpr int NL = (NV + kThreads - 1) / kThreads;
     float4 v[NL];
     float tail_v = 0.f, z_v = 0.f;
     if (dc != nullptr && tid < HIST) {                              // last 50 inputs of each leg + state
-        tail_v = xc[total - 1 - tid];                               // interleaved: leg = (total-1-tid) % CH
+        tail_v = xc[lay.at(total - 1 - tid)];                       // interleaved: leg = (total-1-tid) % CH
         z_v = state[(int64_t)c * HIST + tid];
     }
 #pragma unroll
@@ -586,14 +596,18 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         // into the next tile's samples made this kernel fetch 1.5x its input (profiles/r02_c_hbm_traffic.md)
         const int q = (tid + kThreads * it < NV) ? tid + kThreads * it : NV - 1;
         const int64_t e = t0 - HP + 4 * (int64_t)q;                 // total % 4 == 0: whole quads are in or out
-        v[it] = *reinterpret_cast<const float4*>(xc + (e < 0 ? 0 : (e > total - 4 ? total - 4 : e)));
+        v[it] = *reinterpret_cast<const float4*>(xc + lay.at(e < 0 ? 0 : (e > total - 4 ? total - 4 : e)));
     }
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
         const int q = tid + kThreads * it;
         const int64_t e = t0 - HP + 4 * (int64_t)q;
-        if (q < NV)
-            *reinterpret_cast<float4*>(&x_s[xpos(4 * q)]) = (e >= 0 && e < total) ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < NV) {
+            const float4 val = (e >= 0 && e < total) ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v2f* dst = reinterpret_cast<v2f*>(&x_s[xpos(4 * q)]);       // 8-byte aligned (groups of 10 dwords)
+            dst[0] = v2f{val.x, val.y};
+            dst[1] = v2f{val.z, val.w};
+        }
     }
     __syncthreads();
     float mean = 0.f;
@@ -622,23 +636,36 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         mean = tot / (float)total;
     }
     const int o = tid * PER;
-    float w[NW * 4];
+    // y[e0 + r] = sum_j b[j] z[e0 + r - CH j]: tap j reads the 8-value span that starts CH j below the outputs, so
+    // the span slides down by CH values per tap.  It lives in a circular register buffer of 8 + 2 CH values whose
+    // slot numbers are compile-time constants (the loop is fully unrolled: no register moves); the CH values the
+    // next tap adds are read from LDS one tap ahead.  ~30 VGPRs instead of the 108-value window: twice the waves.
+    constexpr int RB = PER + 2 * CH;                                // ring size; value at offset d sits in slot d mod RB
+    auto slot = [](int d) -> int { return ((d % RB) + RB) % RB; };
+    float ring[RB];
+    auto fill = [&](int d) {                                        // loads values d .. d + CH - 1 (relative to e0)
+        if constexpr (CH == 2) {
+            v2f q = *reinterpret_cast<const v2f*>(&x_s[xpos(o + HP + d)]);   // d even: the pair never crosses a pad
+            asm volatile("" : "+v"(q));
+            ring[slot(d)] = q.x;
+            ring[slot(d + 1)] = q.y;
+        } else {
+            float q = x_s[xpos(o + HP + d)];
+            asm volatile("" : "+v"(q));
+            ring[slot(d)] = q;
+        }
+    };
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        float4 q4 = *reinterpret_cast<const float4*>(&x_s[xpos(o + 4 * j)]);
-        asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w));   // keep the 16-byte reads
-        w[4 * j] = q4.x;
-        w[4 * j + 1] = q4.y;
-        w[4 * j + 2] = q4.z;
-        w[4 * j + 3] = q4.w;
-    }
+    for (int d = 0; d < PER; d += CH) fill(d);                      // the span of tap 0
+    fill(-CH);                                                      // ... and what tap 1 adds
     float acc[PER];
 #pragma unroll
     for (int r = 0; r < PER; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int j = 0; j <= 50; ++j) {
+        if (j + 2 <= 50) fill(-CH * (j + 2));                       // two taps ahead: its slots were freed by tap j - 1 ...
 #pragma unroll
-        for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], w[r + HP - CH * j], acc[r]);
+        for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], ring[slot(r - CH * j)], acc[r]);
     }
     float local = 0.f;
     const int64_t e0 = t0 + o;
@@ -677,11 +704,11 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
 
 __global__ __launch_bounds__(128) void k_fir_state(const float* __restrict__ x, int64_t n, int ch,
                                                    const float* __restrict__ taps, int nb,
-                                                   float* __restrict__ state) {
+                                                   float* __restrict__ state, RowLayout lay) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* z_old = smem;  // nb - 1
     const int h = blockIdx.x % ch, c = blockIdx.x / ch;
-    const float* xc = x + (int64_t)c * n * ch + h;
+    const float* xc = x + (int64_t)c * lay.signal_stride;
     float* zc = state + ((int64_t)c * ch + h) * (nb - 1);
     for (int s = threadIdx.x; s < nb - 1; s += blockDim.x) z_old[s] = zc[s];
     __syncthreads();
@@ -689,7 +716,7 @@ __global__ __launch_bounds__(128) void k_fir_state(const float* __restrict__ x, 
         // zf[s] = sum_i b[s+1+i] x[n-1-i]  (+ what is left of the old state when n < nb-1)
         float acc = 0.f;
         const int64_t cnt = (nb - 1 - s) < n ? (nb - 1 - s) : n;
-        for (int64_t i = 0; i < cnt; ++i) acc = fmaf(taps[s + 1 + i], xc[(n - 1 - i) * ch], acc);
+        for (int64_t i = 0; i < cnt; ++i) acc = fmaf(taps[s + 1 + i], xc[lay.at((n - 1 - i) * ch + h)], acc);
         if (s + n < nb - 1) acc += z_old[s + n];
         zc[s] = acc;
     }
@@ -850,24 +877,33 @@ void launch_fir(const float* x, float* y, int64_t n, int ch, int batch, const fl
 
 int fir51_tiles(int64_t n, int ch) { return (int)((n * ch + kFirFastTile - 1) / kFirFastTile); }
 
+static RowLayout row_layout(int64_t n, int ch, int row_samples, int row_pitch_samples) {
+    if (row_samples <= 0 || row_pitch_samples == row_samples) return RowLayout{0, 0, n * ch};
+    RC_REQUIRE(n % row_samples == 0 && (row_samples * ch) % 4 == 0 && (row_pitch_samples * ch) % 4 == 0,
+               RCFM_ERR_RUNTIME, "padded audio rows must hold whole 16-byte quads");
+    return RowLayout{row_samples * ch, row_pitch_samples * ch, (n / row_samples) * (int64_t)row_pitch_samples * ch};
+}
+
 void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const float* taps_host,
-                  const float* state, float* partial, const float2* dc, hipStream_t stream) {
+                  const float* state, float* partial, const float2* dc, hipStream_t stream, int row_samples,
+                  int row_pitch_samples) {
     if (batch <= 0 || n <= 0) return;
     DeemphTaps taps;
     for (int i = 0; i < 51; ++i) taps.b[i] = taps_host[i];
+    const RowLayout lay = row_layout(n, ch, row_samples, row_pitch_samples);
     const dim3 grid((unsigned)fir51_tiles(n, ch), (unsigned)batch, 1);
     if (ch == 2)
-        hipLaunchKernelGGL(k_fir51<2>, grid, dim3(kThreads), 0, stream, x, y, n * 2, taps, state, partial, dc);
+        hipLaunchKernelGGL(k_fir51<2>, grid, dim3(kThreads), 0, stream, x, y, n * 2, taps, state, partial, dc, lay);
     else
-        hipLaunchKernelGGL(k_fir51<1>, grid, dim3(kThreads), 0, stream, x, y, n, taps, state, partial, dc);
+        hipLaunchKernelGGL(k_fir51<1>, grid, dim3(kThreads), 0, stream, x, y, n, taps, state, partial, dc, lay);
     RC_LAUNCH_CHECK();
 }
 
 void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
-                      float* state, hipStream_t stream) {
+                      float* state, hipStream_t stream, int row_samples, int row_pitch_samples) {
     if (batch <= 0 || nb < 2) return;
     hipLaunchKernelGGL(k_fir_state, dim3((unsigned)(batch * ch)), dim3(128), sizeof(float) * (nb - 1), stream,
-                       x, n, ch, taps, nb, state);
+                       x, n, ch, taps, nb, state, row_layout(n, ch, row_samples, row_pitch_samples));
     RC_LAUNCH_CHECK();
 }
 
