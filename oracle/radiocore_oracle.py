@@ -487,6 +487,7 @@ class Tuner:
 
     def __init__(self, cuda=False):
         self._win = None
+        self._win_len = None          # run_pruned never builds the window: only its length is remembered
         self._buffer = None
         self._input_frequency = 0.0
         self._input_bandwidth = 0.0
@@ -528,12 +529,19 @@ class Tuner:
         roll, m = self._roll(channel_index)
         if self._win is None:
             self._win = shifted_window("hann", int(self._input_bandwidth))
+        if self._win.shape[0] != self._buffer.shape[0]:
+            # scipy.signal.resample's check: the reference caches its window at the first run (tuner.py:155-157)
+            raise ValueError("window must have the same length as data")
         tmp = np.roll(self._buffer, roll)
         return resample(tmp, m, window=self._win, domain="freq")
 
     def run_pruned(self, channel_index):
         roll, m = self._roll(channel_index)
         n = self._buffer.shape[0]
+        if self._win_len is None:
+            self._win_len = int(self._input_bandwidth)
+        if (self._win.shape[0] if self._win is not None else self._win_len) != n:
+            raise ValueError("window must have the same length as data")
         if m > n:
             return self.run(channel_index)
         Y = tuner_channel_spectrum(self._buffer, n, roll, m)

@@ -1,6 +1,7 @@
 // C ABI of librcfm.so (include/rcfm.h): handles, host-side filter / window design,
 // and the per-chunk kernel chains of Tuner.run and FM / MFM / WBFM.run.
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -171,8 +172,11 @@ const char* const kStageNames[ST_COUNT] = {
     "rfft_B",        "hilbert_mask",  "ifft_B",       "stereo_mix",    "fft_B",
     "audio_spectrum", "ifft_A",       "deemphasis",   "deemph_state",  "dc_clip"};
 
+// One process-wide instance; handles of different threads may time stages concurrently, so every access goes
+// through `mu` (uncontended in the single-DSP-thread use the reference has).
 struct Profiler {
-    uint64_t mask = 0;
+    std::mutex mu;
+    std::atomic<uint64_t> mask{0};
     struct Pair {
         hipEvent_t a, b;
     };
@@ -181,8 +185,9 @@ struct Profiler {
     double total_ms[ST_COUNT] = {};
     int64_t count[ST_COUNT] = {};
 
-    bool on(int st) const { return (mask >> st) & 1u; }
+    bool on(int st) const { return (mask.load(std::memory_order_relaxed) >> st) & 1u; }
     Pair take() {
+        std::lock_guard<std::mutex> lock(mu);
         if (!pool.empty()) {
             Pair p = pool.back();
             pool.pop_back();
@@ -193,7 +198,12 @@ struct Profiler {
         RC_HIP(hipEventCreate(&p.b));
         return p;
     }
+    void push(int st, Pair p) {
+        std::lock_guard<std::mutex> lock(mu);
+        pending[st].push_back(p);
+    }
     void collect() {
+        std::lock_guard<std::mutex> lock(mu);
         for (int st = 0; st < ST_COUNT; ++st) {
             for (auto& p : pending[st]) {
                 RC_HIP(hipEventSynchronize(p.b));
@@ -225,7 +235,7 @@ struct StageTimer {
     ~StageTimer() {
         if (live) {
             (void)hipEventRecord(p.b, s);
-            g_prof.pending[st].push_back(p);
+            g_prof.push(st, p);
         }
     }
 };
@@ -1471,6 +1481,7 @@ int rcfm_profile_enable(uint64_t stage_mask) {
 int rcfm_profile_reset(void) {
     return guarded([&] {
         g_prof.collect();
+        std::lock_guard<std::mutex> lock(g_prof.mu);
         for (int i = 0; i < ST_COUNT; ++i) {
             g_prof.total_ms[i] = 0.0;
             g_prof.count[i] = 0;
@@ -1482,6 +1493,7 @@ int rcfm_profile_read(int stage, double* total_ms, int64_t* launches) {
     return guarded([&] {
         RC_REQUIRE(stage >= 0 && stage < ST_COUNT && total_ms && launches, RCFM_ERR_ARG, "bad stage");
         g_prof.collect();
+        std::lock_guard<std::mutex> lock(g_prof.mu);
         *total_ms = g_prof.total_ms[stage];
         *launches = g_prof.count[stage];
     });

@@ -10,6 +10,8 @@ torch.cuda.current_stream); no torch operator computes any part of the path.
 
 import ctypes
 import os
+import sys
+import warnings
 
 import numpy as np
 
@@ -209,9 +211,14 @@ class Handle:
         self._destroy = destroy
 
     def __del__(self):
+        if not self.value:
+            return
         try:
-            if self.value:
-                self._destroy(self.value)
-                self.value = None
-        except Exception:
-            pass
+            status = self._destroy(self.value)
+        except Exception as e:        # interpreter shutdown: the library or ctypes may already be gone
+            if not sys.is_finalizing():
+                warnings.warn("librcfm handle could not be destroyed: %r" % (e,), ResourceWarning)
+            return
+        self.value = None
+        if status != 0 and not sys.is_finalizing():
+            warnings.warn("librcfm destroy returned status %d" % status, ResourceWarning)

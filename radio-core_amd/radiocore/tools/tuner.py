@@ -52,6 +52,7 @@ class Tuner(Injector):
         self._handle_key = None
         self._shard = None         # (first, count) declared by shard()
         self._loaded_size = None
+        self._win_size = None      # length of the reference's cached window (set by the first run)
         self._batched = None       # (key, demod handle) of run_all
 
     @property
@@ -141,8 +142,12 @@ class Tuner(Injector):
     def _ready(self):
         if self._loaded_size is None:
             raise RuntimeError("Tuner.run called before Tuner.load")
-        if self._loaded_size != int(self._input_bandwidth):
-            # scipy.signal.resample's check in the reference (window vs data length)
+        # tuner.py:155-157 builds the spectral window on the first run() with int(input_bandwidth) points and never
+        # refreshes it; scipy.signal.resample then refuses any buffer of another length -- also after a later
+        # request_bandwidth().  Same behaviour here: the first run fixes the size.
+        if self._win_size is None:
+            self._win_size = int(self._input_bandwidth)
+        if self._loaded_size != self._win_size:
             raise ValueError('window must have the same length as data')
         return self._device_tuner(self._loaded_size)
 

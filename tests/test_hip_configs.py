@@ -187,10 +187,11 @@ def test_cfg5_full_size_fm(rc, oracle):
 
 
 def test_cfg4_full_size_wbfm(rc, oracle):
-    """BASELINE configs[3] (the bench workload): N = 240 000 000 -> 1024 x WBFM; the ends and both sides of
-    the 512-channel chunk boundary."""
+    """BASELINE configs[3] (the bench workload): N = 240 000 000 -> 1024 x WBFM; the ends and the middle (the
+    512-channel chunk boundary of explicit chunking), two buffers: the second one exercises the per-channel
+    de-emphasis state of the batched pipeline at full size."""
     sample = [0, 511, 512, 1023]
-    errs, iq_err, _, _, _ = _full_config(rc, oracle, "cfg4", sample)
+    errs, iq_err, _, _, _ = _full_config(rc, oracle, "cfg4", sample, buffers=2)
     print("cfg4", errs, iq_err)
     assert iq_err <= TOL
     assert max(errs.values()) <= TOL, errs

@@ -231,6 +231,11 @@ def test_errors_match_the_reference(rc):
         rc.Tuner().reset()
 
 
+def test_tuner_keeps_its_first_window(rc):
+    from test_oracle_golden import _stale_window_scenario
+    _stale_window_scenario(rc)
+
+
 def test_device_output_and_reset(rc):
     import torch
     B, A = 60000, 12000

@@ -72,6 +72,38 @@ def test_fm_off_centre_carrier(golden):
         assert abs(vs_truth - ref_vs_truth) <= 0.05 * ref_vs_truth
 
 
+def _stale_window_scenario(impl):
+    """tuner.py:155-157: the spectral window is built by the first run() and never refreshed, so after a later
+    request_bandwidth() buffers of the NEW size are refused and buffers of the old size still work (observed on the
+    reference itself: 'window must have the same length as data' from scipy.signal.resample)."""
+    import numpy as np
+    t = impl.Tuner()
+    t.add_channel(1e6, 100, None)
+    t.add_channel(1.0005e6, 100, None)
+    t.request_bandwidth(1000.0)
+    x1 = np.random.default_rng(0).standard_normal(1000).astype(np.complex64)
+    x2 = np.random.default_rng(1).standard_normal(2000).astype(np.complex64)
+    t.load(x1)
+    first = np.asarray(t.run(0))
+    assert first.shape == (100,)
+    t.request_bandwidth(2000.0)
+    t.load(x2)
+    with pytest.raises(ValueError, match="window must have the same length as data"):
+        t.run(0)
+    t.load(x1)
+    assert np.array_equal(np.asarray(t.run(0)), first)
+    fresh = impl.Tuner()
+    fresh.add_channel(1e6, 100, None)
+    fresh.request_bandwidth(1000.0)
+    fresh.load(x2)                                   # wrong size from the start: refused at the first run
+    with pytest.raises(ValueError, match="window must have the same length as data"):
+        fresh.run(0)
+
+
+def test_tuner_keeps_its_first_window():
+    _stale_window_scenario(oracle)
+
+
 def test_size_mismatch_raises():
     import numpy as np
     for cls in (oracle.FM, oracle.MFM, oracle.WBFM):
