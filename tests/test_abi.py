@@ -65,6 +65,14 @@ def test_argument_errors_need_no_device(lib):
     assert lib.rcfm_demod_create(7, 1, 100, 10, ctypes.c_double(75e-6), 0, ctypes.byref(out)) == -4
     lib.rcfm_last_error.restype = ctypes.c_char_p
     assert b"kind" in lib.rcfm_last_error()
+    # ingest and gather entry points (round 2)
+    assert lib.rcfm_feeder_create(ctypes.c_size_t(0), 2, None, ctypes.byref(out)) == -4
+    assert lib.rcfm_feeder_create(ctypes.c_size_t(1024), 0, None, ctypes.byref(out)) == -4
+    assert lib.rcfm_feeder_submit(None, None) == -4
+    assert lib.rcfm_host_register(None, ctypes.c_size_t(16)) == -4
+    assert lib.rcfm_comm_init_rank(2, 2, None, ctypes.byref(out)) == -4
+    assert lib.rcfm_gather_audio(None, 0, None, ctypes.c_size_t(0), None, None) == -4
+    assert lib.rcfm_tuner_shard(None, 0, 0) == -4
 
 
 def test_package_fails_loudly_without_a_device():

@@ -84,3 +84,17 @@ def test_engine_vs_rocfft_full_wideband(n):
     e_t = float(torch.sum(x.real.double() ** 2 + x.imag.double() ** 2))
     e_f = float(torch.sum(a.real.double() ** 2 + a.imag.double() ** 2)) / n
     assert abs(e_f - e_t) <= 1e-5 * e_t
+
+
+@pytest.mark.parametrize("n,plan", [(384000, "640,600"), (375000, "600,625"), (400000, "625,640")])
+def test_big_tiles_in_both_roles(n, plan, monkeypatch):
+    """The 600 / 625 / 640-point tiles (two 1024-thread workgroups per CU, twiddles as powers of one global table
+    entry, XOR-swizzled rows image) in the roles the hot-path plans do not use them in: the planner's wideband plans
+    run 600 and 625 strided and 640 as rows; forced two-pass plans here run 640 and 625 strided and 600, 625, 640 as
+    rows.  (RCFM_FFT_FORCE is read when the engine of a length is first built.)"""
+    monkeypatch.setenv("RCFM_FFT_FORCE", plan)
+    r = np.random.default_rng(n)
+    x = (r.standard_normal((2, n)) + 1j * r.standard_normal((2, n))).astype(np.complex64)
+    want = np.fft.fft(x.astype(np.complex128), axis=1).astype(np.complex64)
+    assert rel_err(_run(n, 2, False, x), want) <= 2e-6
+    assert rel_err(_run(n, 2, True, want), x * n) <= 4e-6

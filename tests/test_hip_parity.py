@@ -184,6 +184,18 @@ def test_sharded_tuner_keeps_what_its_channels_read(rc, oracle):
             assert np.array_equal(part.run(i), full.run(i)), (first, i)
     with pytest.raises(IndexError):
         part.shard(6, 3)
+    # the range that counts is the one the spectrum was LOADED for: re-declaring the shard without a new load does
+    # not make the other rows appear (rcfm_tuner_run checks against the loaded range)
+    part.shard(0, 3)
+    part.load(x)
+    part.shard(5, 3)
+    with pytest.raises(RuntimeError, match="outside the shard"):
+        part.run(6)
+    assert np.array_equal(part.run(1), full.run(1))
+    part.load(x)                                   # now the new range is in force
+    assert np.array_equal(part.run(6), full.run(6))
+    with pytest.raises(RuntimeError, match="outside the shard"):
+        part.run(1)
 
 
 def test_tuner_spectrum_bins(rc, golden):
@@ -356,6 +368,18 @@ def test_feeder_overlaps_copies_and_matches_synchronous_load(rc):
     for k in range(K):
         assert np.array_equal(got[k][0], want[k][0]), k
         assert np.array_equal(got[k][1], want[k][1]), k
+    # pageable memory pinned in place with rcfm_host_register works as a source too
+    import ctypes
+    from radiocore._internal import hip
+    plain = np.ascontiguousarray(hosts[2].data.copy())
+    hip.check(hip.lib().rcfm_host_register(ctypes.c_void_p(plain.ctypes.data), plain.nbytes))
+    feeder.submit(plain)
+    with feeder.next() as x:
+        fed.load(x)
+        assert np.array_equal(fed.run(1), want[2][0])
+    import torch
+    torch.cuda.synchronize()
+    hip.check(hip.lib().rcfm_host_unregister(ctypes.c_void_p(plain.ctypes.data)))
     # protocol errors are reported, not ignored
     feeder.submit(hosts[0].data)
     feeder.submit(hosts[1].data)
