@@ -550,8 +550,8 @@ struct DeemphTaps {
 struct RowLayout {
     int row_len, row_pitch;
     int64_t signal_stride;     // values between consecutive signals
-    __device__ __forceinline__ int64_t at(int64_t e) const {
-        return row_len ? e + (e / row_len) * (int64_t)(row_pitch - row_len) : e;
+    __device__ __forceinline__ int64_t at(int64_t e) const {   // e in [0, 2^31): 32-bit division
+        return row_len ? e + (int64_t)((unsigned)e / (unsigned)row_len) * (row_pitch - row_len) : e;
     }
 };
 
