@@ -195,3 +195,44 @@ def test_cfg4_full_size_wbfm(rc, oracle):
     print("cfg4", errs, iq_err)
     assert iq_err <= TOL
     assert max(errs.values()) <= TOL, errs
+
+
+@pytest.mark.parametrize("kind", ["WBFM", "MFM"])
+def test_run_all_on_an_untidy_band(rc, oracle, kind):
+    """A wideband buffer that is not the tidy recipe of the other tests: stations of unequal strength (14 dB apart),
+    carriers a few tens of Hz off their channel centres (small enough that the reference's float32 unwrap, fm.py:62,
+    stays below 2e-5 -- DESIGN.md section 6 covers the large-offset case), a strong station next to a weak one on
+    overlapping channels, one channel that holds nothing but noise, more noise overall."""
+    N, B, A, C = 2_400_000, 60000, 12000, 9
+    centres = workloads.channel_grid(C, 50000)               # 60 kHz channels on a 50 kHz raster: neighbours overlap
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    f_in = ref.input_frequency
+    gains = [0.9, 0.2, 0.6, 0.25, 0.0, 1.0, 0.18, 0.7, 0.45]
+    offsets = [0, 37, -52, 11, 0, -23, 60, -8, 41]
+    rng = np.random.default_rng(99)
+    Xw = np.zeros(N, np.complex128)
+    kk = np.fft.fftfreq(B, 1.0 / B).astype(np.int64)
+    for i, fc in enumerate(centres):
+        if gains[i] == 0.0:
+            continue                                          # channel 4: noise only
+        s = workloads.station_iq(20 + i, B, stereo=(kind == "WBFM"), offset=offsets[i])
+        np.add.at(Xw, (kk + int(fc - f_in)) % N, np.fft.fft(s) * (0.3 * gains[i] * N / B))
+    x = np.fft.ifft(Xw) + 0.01 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+    x = x.astype(np.complex64)
+    ch = 2 if kind == "WBFM" else 1
+    for buf in range(2):
+        xb = np.roll(x, 7777 * buf)
+        tuner.load(xb)
+        ref.load(xb)
+        audio = tuner.run_all()
+        for c in ref.channels():
+            iq = ref.run_pruned(c.index)
+            assert rel_err(tuner.run(c.index), iq) <= TOL, (kind, buf, c.index)
+            want = np.asarray(c.demodulator.run(iq)).reshape(A, ch)
+            if gains[c.index] == 0.0:
+                # noise only: the phase steps are uniform in (-pi, pi), so the wrap at +-pi (and, for WBFM, the
+                # carrier regeneration from a noise "pilot") turns float32 rounding into O(1) differences in the
+                # reference itself -- only the linear part (the tuner's IQ, above) is comparable
+                assert np.all(np.isfinite(audio[c.index]))
+                continue
+            assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index, rel_err(audio[c.index], want))
