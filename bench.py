@@ -220,6 +220,24 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0):
     }
 
 
+def measure_cfg1_cpu(reps=5):
+    """BASELINE configs[0]: 1-channel MFM 240 kSPS -> 48 kSPS on the CPU (plumbing, no GPU).  The product has no CPU
+    path: this times the oracle, like cpu_baseline does."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import radiocore_oracle as oracle
+    import workloads
+    x = workloads.single_channel(240_000, i=0)
+    d = oracle.MFM(240_000, 48_000)
+    d.run(x)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d.run(x)
+    dt = (time.perf_counter() - t0) / reps
+    return {"workload": "cfg1: 1-channel MFM 240000 -> 48000 on one host thread (oracle, kind: port)",
+            "ms_per_step": round(dt * 1e3, 3), "value": round(240_000 / dt / 1e6, 3), "unit": "Msamples/s", "steps": reps,
+            "parity": "tests/test_oracle_golden.py::test_mfm"}
+
+
 def measure_batched_cfg2(lib, hip, steps, warmup, T=1024):
     """BASELINE configs[1] (one 240 kSPS WBFM channel) is 13.4 MB of algorithmic traffic: latency-bound as one
     call.  Its bandwidth is measured SURVEY.md section 8d's way: T consecutive buffers as T channels of one
@@ -509,6 +527,7 @@ def main():
             "cfg3": measure_config("cfg3", lib, hip, 50, 5),
             "cfg5": measure_config("cfg5", lib, hip, 20, 3),
             "cfg2_batched": measure_batched_cfg2(lib, hip, 10, 2),
+            "cfg1_cpu": measure_cfg1_cpu(),
         }
     if rank == 0:
         print(json.dumps(result))
