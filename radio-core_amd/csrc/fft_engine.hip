@@ -90,9 +90,11 @@ bool split(int64_t n, int np, int max_l, int64_t* f, double* best_cost = nullptr
             double cost = (double)mx / (double)mn;
             for (int i = 0; i < np; ++i) {
                 if (!is_fast_length(cur[i])) cost += 3.0;   // no compile-time specialised kernel
-                // residency of the tile: up to ~426 points three (or more) workgroups share a CU, the big tiles run
-                // as two 1024-thread workgroups, 427..512 points as two 512-thread ones -- the slowest of the three
-                // per byte (N = 1e8: 400 x 625 x 400 runs 8 % faster than 400 x 500 x 500)
+                // measured per-byte efficiency of the tile classes (plain passes, MI355X): tiles of <= 426 points and the
+                // big tiles (two 1024-thread workgroups per CU) move 5.1-5.2 TB/s, the 427..512-point tiles (two
+                // 512-thread workgroups, 100+ VGPRs) 4.1-4.9: N = 1e8 runs 8 % faster as 400 x 625 x 400 than as
+                // 400 x 500 x 500.  (Forcing three workgroups per CU on the 400-point tiles -- 80 VGPRs, swizzled rows --
+                // measured 20 % SLOWER: the weights are empirical, not an occupancy model.)
                 if (cur[i] > kFftMaxL) cost += 0.15;
                 else if (cur[i] > 426) cost += 0.35;
             }
