@@ -930,14 +930,20 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
         RC_REQUIRE(t && x, RCFM_ERR_ARG, "NULL argument");
         {
             StageTimer tm(ST_TUNER_FFT, as_stream(stream));
+            bool halo_done = false;
             if (t->forward_engine) {
+                // the last pass writes the halos itself (bins near both ends are stored twice): no copy launches
+                FftRowWindow w = t->windowed ? t->window
+                                             : FftRowWindow{0, (int)(t->n / t->forward_engine->row_length()) - 1, 0};
+                w.halo = (int)t->halo;
+                halo_done = t->halo > 0;
                 t->forward_engine->c2c(static_cast<const float2*>(x), t->spectrum(), t->forward_tmp.as<float2>(),
-                                       1, false, 1.0f, as_stream(stream), t->windowed ? &t->window : nullptr);
+                                       1, false, 1.0f, as_stream(stream), &w);
             } else {
                 t->work.reserve(t->forward->work_bytes());
                 t->forward->exec(const_cast<void*>(x), t->spectrum(), t->work.get(), as_stream(stream));
             }
-            if (t->halo) {
+            if (t->halo && !halo_done) {
                 float2* X = t->spectrum();
                 const size_t hb = sizeof(float2) * (size_t)t->halo;
                 RC_HIP(hipMemcpyAsync(X - t->halo, X + t->n - t->halo, hb, hipMemcpyDeviceToDevice, as_stream(stream)));

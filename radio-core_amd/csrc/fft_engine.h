@@ -82,6 +82,9 @@ struct FftPassDev {
 // pass length): lo <= hi keeps rows lo..hi, lo > hi keeps rows >= lo and rows <= hi (a window that wraps).
 struct FftRowWindow {
     int lo, hi;
+    // halo > 0 (batch 1, forward): outputs [0, halo) are also stored at out[n + g], outputs [n - halo, n) at
+    // out[g - n] -- `out` must have `halo` elements of room on both sides.  lo = 0, hi = rows - 1 keeps every row.
+    int halo = 0;
 };
 
 class FftEngine {

@@ -370,7 +370,8 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<true>{out, scale}, stream);
             else if (keep != nullptr)
                 launch_fft_pass<kRowsOnly>(dev, batch, ld,
-                                           StoreRowWindow{out, scale, (int)dev.p.n_o1, (int)dev.p.n_o2, keep->lo, keep->hi},
+                                           StoreRowWindow{out, scale, (int)dev.p.n_o1, (int)dev.p.n_o2, keep->lo, keep->hi,
+                                                          n, batch == 1 ? keep->halo : 0},
                                            stream);
             else
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<false>{out, scale}, stream);

@@ -1430,10 +1430,21 @@ struct StoreRowWindow {
     float2* out;
     float scale;
     int n_o1, n_o2, lo, hi;
+    // halo > 0 (single transforms only): the first `halo` outputs are repeated behind the end and the last `halo` in
+    // front of the start (out[n + g] and out[g - n]): the tuner's haloed spectrum without two extra copy launches.
+    int64_t n = 0;
+    int halo = 0;
     __device__ __forceinline__ void operator()(const LineId& id, int k, int64_t base, unsigned off, float2 v) const {
         const int row = (int)id.o1 + n_o1 * ((int)id.o2 + n_o2 * k);
         const bool keep = lo <= hi ? (row >= lo && row <= hi) : (row >= lo || row <= hi);
-        if (keep) stream_store(out + base + off, make_float2(v.x * scale, v.y * scale));
+        if (!keep) return;
+        const float2 y = make_float2(v.x * scale, v.y * scale);
+        const int64_t g = base + off;
+        stream_store(out + g, y);
+        if (halo > 0) {
+            if (g < halo) out[n + g] = y;
+            else if (g >= n - halo) out[g - n] = y;
+        }
     }
 };
 
