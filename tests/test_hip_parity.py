@@ -387,3 +387,30 @@ def test_feeder_overlaps_copies_and_matches_synchronous_load(rc):
         feeder.submit(hosts[2].data)
     with pytest.raises(ValueError, match="size"):
         feeder.submit(np.zeros(10, np.complex64))
+
+
+def test_server_loop_example(rc, oracle):
+    """examples/multi_fm_pipeline.py: producer thread -> RingBuffer -> Feeder -> Tuner.run_all -> wire frames, three
+    seconds; every published message equals the oracle's audio for that second and channel."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("multi_fm_pipeline", os.path.join(ROOT, "examples", "multi_fm_pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seconds, C, rate, B, A = 3, 5, 1_200_000, 60000, 12000
+    msgs = mod.run(seconds, C, rate, B, A)
+    assert len(msgs) == seconds * C
+    centres = workloads.channel_grid(C, 50000)
+    ref = oracle.Tuner()
+    for f in centres:
+        ref.add_channel(f, B, oracle.WBFM(B, A))
+    ref.request_bandwidth(float(rate))
+    second = workloads.wideband(rate, ref.input_frequency, centres, B, gain=0.3)
+    for s in range(seconds):
+        ref.load(np.roll(second, 1000 * s))
+        for c in ref.channels():
+            freq, pcm = msgs[s * C + c.index]
+            assert freq == int(c.center_frequency)
+            want = c.demodulator.run(ref.run_pruned(c.index))[0]
+            assert rel_err(pcm, want) <= TOL, (s, c.index)
