@@ -339,7 +339,10 @@ struct rcfm_tuner_s {
     bool phase_capable(int first) { return first >= 0 && first < nch && band(bw[first]).engine != nullptr; }
 
     // theta != nullptr (phase_capable bands only): angle(x) / pi goes to theta [count][B] float32, out is unused.
-    void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr) {
+    // First pass length n_1 of the band's inverse FFT (0 without an engine): its last pass stores rows of n_1 samples.
+    int band_row_length(int first) { return phase_capable(first) ? (int)band(bw[first]).engine->row_length() : 0; }
+
+    void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr, int theta_pitch = 0) {
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
         RC_REQUIRE(loaded, RCFM_ERR_STATE, "rcfm_tuner_run called before rcfm_tuner_load");
         RC_REQUIRE(!loaded_windowed || (first >= loaded_first && first + count <= loaded_first + loaded_count),
@@ -357,7 +360,7 @@ struct rcfm_tuner_s {
             TunerGather tg{spectrum(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode,
                            halo ? base_dev.as<int32_t>() + first : nullptr, halo};
             StageTimer tm(ST_TUNER_IFFT, s);
-            fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s, theta);
+            fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s, theta, theta_pitch);
             return;
         }
         RC_REQUIRE(theta == nullptr, RCFM_ERR_STATE, "phase output needs the FFT engine");
@@ -505,7 +508,8 @@ struct rcfm_demod_s {
     // Does run_chunk take the samples' phases (theta = angle(x) / pi, float32 [cnt][B]) instead of iq?
     bool phase_capable() const { return eng_B != nullptr && (kind != RCFM_WBFM || B % 4 == 0); }
 
-    void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s, const float* theta = nullptr) {
+    void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s, const float* theta = nullptr,
+                   PhaseRows rows = PhaseRows{}) {
         size_t need = 0;
         if (kind == RCFM_WBFM) {
             FftPlan* pf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -673,7 +677,7 @@ struct rcfm_demod_s {
             {
                 StageTimer tm(ST_FFT_REAL_B, s);
                 fused_real_pair_fft_first(*eng_B, theta != nullptr ? theta : d, buf_T.as<float2>(), cnt,
-                                          theta != nullptr, s);
+                                          theta != nullptr, s, rows);
             }
             float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
             {
@@ -694,7 +698,7 @@ struct rcfm_demod_s {
                 // two channels per complex FFT; only |k| <= A/2 is kept (and read back by the unpacking).
                 // From the tuner's phases the discriminator is the load of the first pass.
                 if (theta != nullptr)
-                    fused_real_pair_fft(*eng_B, theta, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s, true);
+                    fused_real_pair_fft(*eng_B, theta, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s, true, rows);
                 else
                     fused_real_pair_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
             }
@@ -1104,9 +1108,24 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                 return e && e[0] == '0';
             }();
             if (!no_phase && d->phase_capable() && t->phase_capable(first + off)) {
+                // FM / MFM read the phases through LoadPhaseStepPair, which understands padded rows: when the tuner's
+                // last pass would store rows of n_1 phases that are not whole 64-byte segments apart (cfg5: n_1 = 100),
+                // the rows go to a pitch of whole 128-byte lines.  (WBFM's pilot stage reads contiguous phases.)
+                PhaseRows rows;
+                const int n1 = t->band_row_length(first + off);
+                static const bool no_pad = [] {
+                    const char* e = std::getenv("RCFM_PHASE_PITCH");
+                    return e && e[0] == '0';
+                }();
+                if (!no_pad && d->kind != RCFM_WBFM && d->eng_B && n1 > 0 && n1 % 16 != 0 && d->B % n1 == 0 &&
+                    d->B < (1 << 20) && n1 < (1 << 12)) {
+                    rows.row = n1;
+                    rows.pitch = (n1 + 15) / 16 * 16;     // floats: a 64-byte store segment never straddles a line
+                    d->buf_iq.reserve((size_t)d->chunk * rows.channel_stride(d->B) * sizeof(float));
+                }
                 float* theta = d->buf_iq.as<float>();
-                t->run(first + off, cnt, nullptr, as_stream(stream), theta);
-                d->run_chunk(first + off, cnt, nullptr, outp + (size_t)off * d->A * d->ch, as_stream(stream), theta);
+                t->run(first + off, cnt, nullptr, as_stream(stream), theta, rows.pitch);
+                d->run_chunk(first + off, cnt, nullptr, outp + (size_t)off * d->A * d->ch, as_stream(stream), theta, rows);
                 continue;
             }
             t->run(first + off, cnt, d->buf_iq.as<float2>(), as_stream(stream));

@@ -26,8 +26,17 @@ struct TunerGather {
 };
 // theta != nullptr: instead of out, angle(ifft) / pi goes to theta [count][B] float32 -- all an FM
 // discriminator needs (fm.py:60-65), and half the bytes.
+// theta_pitch > 0: phase k_1 + n_1 k_2 of a channel goes to theta[k_2 theta_pitch + k_1] (n_1 = e's first pass length; a
+// channel then occupies (B / n_1) theta_pitch values): rows of n_1 = 100 phases start every 400 bytes and their 64-byte
+// store segments straddle lines; at a pitch of 112 they are aligned (PhaseRows describes the layout to the reader).
 void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
-                      hipStream_t s, float* theta = nullptr);
+                      hipStream_t s, float* theta = nullptr, int theta_pitch = 0);
+
+// Layout of a phase array written with theta_pitch: sample t of a channel sits at (t / row) pitch + t % row.
+struct PhaseRows {
+    int row = 0, pitch = 0;            // row = 0: contiguous
+    int64_t channel_stride(int64_t n) const { return row ? (n / row) * (int64_t)pitch : n; }
+};
 
 // Forward FFT of real signals x [count][n] -> full complex spectrum U [count][n].
 // keep >= 0: only bins |k| <= keep are written (the rest of U is left untouched).
@@ -52,7 +61,7 @@ constexpr int kKeepLowerHalf = -2;
 // from_phase: x holds angle / pi of complex samples and the real signals are its wrapped steps -- the FM
 // discriminator (fm.py:60-65) computed on the load, d[0] = 0.
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U2, float2* tmp, int count, int keep,
-                         hipStream_t s, bool from_phase = false);
+                         hipStream_t s, bool from_phase = false, PhaseRows rows = PhaseRows{});
 void fused_hilbert_pair_ifft_mix(const FftEngine& e, const float2* U2, const float* m, float2* u, float2* tmp,
                                  int count, hipStream_t s);
 
@@ -99,7 +108,7 @@ void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2
 // the packed pair is decimated like one complex signal and one inverse transform returns channel 2P in the
 // real part, 2P+1 in the imaginary part: y [count][A] float32; dc [count] receives (sum y_c / A, 0).
 void fused_real_pair_fft_first(const FftEngine& e, const float* x, float2* tmp, int count, bool from_phase,
-                               hipStream_t s);
+                               hipStream_t s, PhaseRows rows = PhaseRows{});
 void fused_fft_decim_ifft_pairs(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float* y,
                                 float2* tmp_a, int count, const float* wr, float scale, float2* dc, hipStream_t s);
 

@@ -155,9 +155,17 @@ struct LoadPhaseStepPair {
     const float* theta;
     int n, count;
     int line_stride;
+    // padded rows (fused_tuner_ifft's theta_pitch): sample t sits at t + (t / row) (pitch - row); magic = ceil(2^32 / row)
+    int row = 0, pad = 0;
+    unsigned magic = 0;
+    int64_t stride = 0;               // values between consecutive channels
+    __device__ __forceinline__ int where(int t) const {
+        return row ? t + (int)__umulhi((unsigned)t, magic) * pad : t;
+    }
     __device__ __forceinline__ float2 at(const LineId& id, int t) const {
         const int c0 = 2 * id.batch, c1 = (c0 + 1 < count) ? c0 + 1 : c0;
-        return make_float2(theta[(int64_t)c0 * n + t], theta[(int64_t)c1 * n + t]);
+        const int i = where(t);
+        return make_float2(theta[(int64_t)c0 * stride + i], theta[(int64_t)c1 * stride + i]);
     }
     __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t, unsigned) const {
         return at(id, l * line_stride + (int)id.i);
@@ -172,6 +180,19 @@ struct LoadPhaseStepPair {
         return make_float2(phase_step_wrapped(a.x, b.x), phase_step_wrapped(a.y, b.y));
     }
 };
+
+LoadPhaseStepPair phase_pair_load(const float* x, int64_t n, int count, int line_stride, const PhaseRows& r) {
+    LoadPhaseStepPair ld{x, (int)n, count, line_stride};
+    ld.stride = r.channel_stride(n);
+    if (r.row > 0 && r.pitch > r.row) {
+        // floor(t / row) = umulhi(t, ceil(2^32 / row)) holds for t * row < 2^32 (t < n <= 2^20 here)
+        RC_REQUIRE(n % r.row == 0 && n < (1 << 20) && r.row < (1 << 12), RCFM_ERR_RUNTIME, "phase rows outside the reader's range");
+        ld.row = r.row;
+        ld.pad = r.pitch - r.row;
+        ld.magic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)r.row - 1) / (uint64_t)r.row);
+    }
+    return ld;
+}
 
 // Hilbert mask applied to one member of such a pair: with U = FFT(x0 + j x1),
 // X0[k] = (U[k] + conj U[-k]) / 2, X1[k] = (U[k] - conj U[-k]) / 2j; Z = h X, bins above n/2 are 0.
@@ -478,7 +499,7 @@ struct StorePhase {
 };
 
 void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, float2* tmp, int count,
-                      hipStream_t s, float* theta) {
+                      hipStream_t s, float* theta, int theta_pitch) {
     if (count <= 0) return;
     const int64_t B = e.desc().n;
     const int np = e.npass();
@@ -526,7 +547,13 @@ void fused_tuner_ifft(const FftEngine& e, const TunerGather& g, float2* out, flo
     middle_passes(e, 1, np - 2, tmp, count, s);
     fftk::LoadPlainT<false> ldl{tmp};
     if (theta != nullptr) {
-        fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), B), count, ldl, StorePhase{theta}, s);
+        FftPassDev last = e.pass_dev(np - 1, e.tmp_stride(), B);
+        if (theta_pitch > 0) {
+            RC_REQUIRE(theta_pitch >= last.p.out_k && last.p.n_o1 * last.p.n_o2 == 1, RCFM_ERR_RUNTIME, "bad phase row pitch");
+            last.out_batch = (B / last.p.out_k) * (int64_t)theta_pitch;
+            last.p.out_k = theta_pitch;
+        }
+        fftk::launch_fft_pass<kRowsOnly>(last, count, ldl, StorePhase{theta}, s);
         return;
     }
     fftk::StorePlainT<true> stl{out, (float)(1.0 / (double)g.N)};   // ifft (1/B) * (B/N)
@@ -574,14 +601,14 @@ void fused_hilbert_ifft(const FftEngine& e, const float2* U, float2* z, float2* 
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 void fused_real_pair_fft(const FftEngine& e, const float* x, float2* U, float2* tmp, int count, int keep,
-                         hipStream_t s, bool from_phase) {
+                         hipStream_t s, bool from_phase, PhaseRows rows) {
     if (count <= 0) return;
     const int64_t n = e.desc().n;
     const int np = e.npass();
     const int pairs = (count + 1) / 2;
     fftk::StorePlainT<false> st0{tmp, 1.0f};
     if (from_phase) {
-        LoadPhaseStepPair ld{x, (int)n, count, (int)e.desc().pass[0].in_l};
+        const LoadPhaseStepPair ld = phase_pair_load(x, n, count, (int)e.desc().pass[0].in_l, rows);
         fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
     } else {
         LoadRealPair ld{x, (int)n, count};
@@ -758,13 +785,13 @@ struct StoreRealImagSplit {
 };
 
 void fused_real_pair_fft_first(const FftEngine& e, const float* x, float2* tmp, int count, bool from_phase,
-                               hipStream_t s) {
+                               hipStream_t s, PhaseRows rows) {
     if (count <= 0) return;
     const int64_t n = e.desc().n;
     const int pairs = (count + 1) / 2;
     fftk::StorePlainT<false> st0{tmp, 1.0f};
     if (from_phase) {
-        LoadPhaseStepPair ld{x, (int)n, count, (int)e.desc().pass[0].in_l};
+        const LoadPhaseStepPair ld = phase_pair_load(x, n, count, (int)e.desc().pass[0].in_l, rows);
         fftk::launch_fft_pass<kStridedOnly>(e.pass_dev(0, 0, e.tmp_stride()), pairs, ld, st0, s);
     } else {
         LoadRealPair ld{x, (int)n, count};
