@@ -451,12 +451,30 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
 #ifndef RCFM_FFT_XCD_ORDER
 #define RCFM_FFT_XCD_ORDER 1
 #endif
-__device__ __forceinline__ unsigned tile_of_block() {
+// Rows of at most this many tiles go to the XCDs as WHOLE rows instead: the blocks of eight consecutive signals form
+// one group, and XCD k takes every tile of the group's k-th signal (an eighth of a short row is one or two tiles --
+// with 8 tiles per row, cfg5's B = 12 500, every neighbour sat on another XCD and each shared line came from HBM twice).
+#ifndef RCFM_FFT_XCD_GROUP_MAX
+#define RCFM_FFT_XCD_GROUP_MAX 15
+#endif
+struct BlockPos {
+    unsigned tile, batch;
+};
+__device__ __forceinline__ BlockPos block_pos() {
+    const unsigned gx = gridDim.x, x = blockIdx.x, z = blockIdx.z;
 #if RCFM_FFT_XCD_ORDER
-    const unsigned gx = gridDim.x, x = blockIdx.x;
-    return (gx & 7u) ? x : (x & 7u) * (gx >> 3) + (x >> 3);
+    if (gx <= RCFM_FFT_XCD_GROUP_MAX) {
+        // linear workgroup id = x + gx (y + gy z); with gy = 1 and z0 = z & ~7 its low three bits are those of
+        // q = x + gx (z & 7), the position inside the group: XCD (q & 7) takes signal z0 + (q & 7), tile q >> 3
+        if (gridDim.y == 1 && (z | 7u) < gridDim.z) {
+            const unsigned q = x + gx * (z & 7u);
+            return BlockPos{q >> 3, (z & ~7u) + (q & 7u)};
+        }
+        return BlockPos{x, z};
+    }
+    return BlockPos{(gx & 7u) ? x : (x & 7u) * (gx >> 3) + (x >> 3), z};
 #else
-    return blockIdx.x;
+    return BlockPos{x, z};
 #endif
 }
 
@@ -616,11 +634,12 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : T >= 512 ? 4 : 1)) void 
     const int w = tid & (W - 1), rg = tid >> 4;
 
     LineId id;
-    id.batch = blockIdx.z;
+    const BlockPos bp = block_pos();
+    id.batch = bp.batch;
     const unsigned o = blockIdx.y, n_o2 = (unsigned)p.n_o2;
     id.o1 = n_o2 == 1 ? o : o / n_o2;
     id.o2 = n_o2 == 1 ? 0 : o - (unsigned)id.o1 * n_o2;
-    const int i0 = (int)tile_of_block() * W;
+    const int i0 = (int)bp.tile * W;
     const int left = (int)p.n_inner - i0;
     // Lanes past the end of a row (last tile only) load line 0 of the tile again and are never stored:
     // every lane transforms its own line, so nothing has to be masked in between.
@@ -848,10 +867,11 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
     const int w = tid & (W - 1), rg = tid >> 4;
 
     LineId id;
-    id.batch = blockIdx.z;
+    const BlockPos bp = block_pos();
+    id.batch = bp.batch;
     id.o1 = 0;
     id.o2 = 0;
-    const int i0 = (int)tile_of_block() * W;
+    const int i0 = (int)bp.tile * W;
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
@@ -1019,13 +1039,14 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
     const int w = tid & (W - 1), rg = tid >> 4;
 
     LineId id;
-    id.batch = blockIdx.z;   // pair index
+    const BlockPos bp = block_pos();
+    id.batch = bp.batch;   // pair index
     id.o1 = 0;
     id.o2 = 0;
-    const int c0 = 2 * (int)blockIdx.z;
+    const int c0 = 2 * (int)bp.batch;
     const bool has1 = c0 + 1 < count;          // an odd count leaves the last pair with one member
     const int c1 = has1 ? c0 + 1 : c0;
-    const int i0 = (int)tile_of_block() * W;
+    const int i0 = (int)bp.tile * W;
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
@@ -1226,10 +1247,11 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
     const int w = tid & (W - 1), rg = tid >> 4;
 
     LineId id;
-    id.batch = blockIdx.z;
+    const BlockPos bp = block_pos();
+    id.batch = bp.batch;
     id.o1 = 0;
     id.o2 = 0;
-    const int i0 = (int)tile_of_block() * W;
+    const int i0 = (int)bp.tile * W;
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
