@@ -1004,9 +1004,10 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
             // Measured on MI355X (profiles/r01_c_chunk_sweep.txt): bigger chunks keep winning -- the kernels are
             // tile-latency bound below ~64 channels per launch, and every launch pays one partial last wave of
             // workgroups: 1024 channels of 240 kHz per launch (9.8 GB of workspace) are 1.3 % faster than 512.
-            // Narrow channels (cfg5: B = 12 500) take proportionally more per launch, up to 2048 (+6 %).
+            // Narrow channels take proportionally more per launch (the same workspace): cfg5 (B = 12 500) measured
+            // 2.23 / 2.10 / 2.06 / 2.05 ms at 1024 / 2048 / 4096 / 8192 channels per launch.
             const char* e = std::getenv("RCFM_CHUNK");
-            const int dflt = (int)std::min<int64_t>(2048, std::max<int64_t>(1024, (int64_t)1024 * 240000 / B));
+            const int dflt = (int)std::min<int64_t>(8192, std::max<int64_t>(1024, (int64_t)1024 * 240000 / B));
             chunk = e ? std::atoi(e) : dflt;
             if (chunk <= 0) chunk = dflt;
         }

@@ -174,9 +174,9 @@ def test_cfg3_full_size_mfm(rc, oracle):
 
 
 def test_cfg5_full_size_fm(rc, oracle):
-    """BASELINE configs[4]: N = 100 000 000 -> 8192 x FM (12.5 kHz -> 8 kHz); channels either side of every
-    2048-channel chunk boundary of the default chunking, and the ends.  A second identical load must give
-    bit-identical audio (FM carries no state)."""
+    """BASELINE configs[4]: N = 100 000 000 -> 8192 x FM (12.5 kHz -> 8 kHz) in one launch per stage (the default
+    for channels this narrow); channels either side of every 2048-channel boundary and the ends.  A second identical
+    load must give bit-identical audio (FM carries no state), in 2048-channel chunks as well."""
     sample = [0, 1, 2047, 2048, 4095, 4096, 6143, 6144, 8190, 8191]
     errs, iq_err, audio, tuner, x = _full_config(rc, oracle, "cfg5", sample)
     print("cfg5", errs, iq_err)
@@ -184,6 +184,7 @@ def test_cfg5_full_size_fm(rc, oracle):
     assert max(errs.values()) <= TOL, errs
     tuner.load(x)
     assert np.array_equal(tuner.run_all(), audio)
+    assert np.array_equal(tuner.run_all(chunk=2048), audio)
 
 
 def test_cfg4_full_size_wbfm(rc, oracle):
