@@ -32,11 +32,11 @@ def main():
         cases = []
         for a in sys.argv[1:]:
             n, _, b = a.partition(":")
-            cases.append((int(n), int(b) if b else 1, 5))
+            cases.append((int(n), int(b) if b else 1, 5 if int(n) > 20_000_000 else 50))
     for n, batch, reps in cases:
         x = torch.view_as_complex(torch.randn(batch * n, 2, device="cuda"))
         y = torch.empty_like(x)
-        for name, fn in (("engine", lib.rcfm_fft_c2c), ("rocfft", lib.rcfm_fft_c2c_rocfft)):
+        for name, fn in (("engine", lib.rcfm_fft_c2c), ("rocfft", lib.rcfm_fft_c2c_rocfft))[:1 if os.environ.get("RCFM_FFT_FORCE") else 2]:
             ms = time_fn(lambda: hip.check(fn(n, batch, 0, hip.ptr(x), hip.ptr(y), hip.stream())), reps)
             gb = 16.0 * n * batch / 1e9
             print("n=%-10d batch=%-5d %-7s %9.3f ms   %7.2f TB/s algorithmic (16 B/point)" %
