@@ -608,17 +608,24 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
 #define RCFM_FFT_PAIR2_MIN (kFftMaxL + 1)
 #endif
 constexpr bool big_tile_pair(int L) { return RCFM_FFT_BIG2 && L >= RCFM_FFT_PAIR2_MIN; }
+// RCFM_FFT_TRIPLE400 (default): the 400-point tile without its twiddle table in LDS is 51 200 B, so THREE 512-thread
+// workgroups fit a CU (<= 80 VGPRs; the rows form spills six dwords).  With the table (54 400 B, 57 600 with the
+// 17-point pitch) only two do.  Measured: cfg5 (400 . 625 . 400 wideband plan) 2.095 -> 2.067 ms, same-box alternation.
+#ifndef RCFM_FFT_TRIPLE400
+#define RCFM_FFT_TRIPLE400 1
+#endif
+constexpr bool triple_tile(int L) { return RCFM_FFT_TRIPLE400 && L == 400; }
 
 // LoadOp contract:  fetch(id, l, tile_base, off) returns element tile_base + off of the input
 //                   (tile_base is workgroup-uniform, off a 32-bit per-lane offset) and does NO
 //                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
 // StoreOp contract: operator()(id, k, tile_base, off, v).
 template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
-__global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
+__global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
                                                                                           StoreOp store) {
     // BIG: two 1024-thread workgroups per CU -- the tile is the whole LDS budget of the workgroup (80 KiB), so the
     // stage twiddles come from the table in global memory (twiddle_powers) and rows tiles use the XOR swizzle.
-    constexpr bool BIG = big_tile_pair(L);
+    constexpr bool BIG = big_tile_pair(L) || triple_tile(L);
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
     constexpr int RL = (S == 2) ? R1 : (S == 3) ? R2 : R3;   // last radix
