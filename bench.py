@@ -292,11 +292,19 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = dist_env()
+    # Dry run of the N > 1 code on a one-GPU box (tests/test_bench_multirank.py): RCFM_BENCH_DEVICE puts every rank on
+    # that device and RCFM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); the audio blocks then
+    # travel through host memory.  The numbers of such a run mean nothing.
+    backend = os.environ.get("RCFM_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("RCFM_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     from radiocore._internal import hip
@@ -340,8 +348,12 @@ def main():
         hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
         # pipeline_run addresses channels of tuner and demod by the same index
         hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audios[slot]), s))
-        if world > 1:                       # RCCL over xGMI: the only collective on the path
+        if world > 1 and backend == "nccl":  # RCCL over xGMI: the only collective on the path
             in_flight[slot] = sharding.gather_audio(audios[slot], C, dst=0, out=gathereds[slot], async_op=True)
+        elif world > 1:                     # dry run: same protocol through host memory
+            got = sharding.gather_audio(audios[slot].cpu(), C, dst=0)
+            if rank == 0:
+                gathereds[slot].copy_(got)
 
     def barrier():
         for i in range(nbuf):
@@ -387,7 +399,7 @@ def main():
     lib.rcfm_profile_enable(ctypes.c_uint64(0))
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -458,6 +470,19 @@ def main():
             "note": "all %d channels' samples / (step time - the replicated wideband FFT, %.3f ms on rank 0)" % (C, fft_ms)}
         alg_fft, alg_all = 16.0 * N, path_bytes(N, C, B, A, kind)
         result["amdahl_bound_speedup"] = round(alg_all / (alg_fft + (alg_all - alg_fft) / world), 3)
+
+        # the last gathered block (outside the timed region): every rank's rows arrived
+        step()
+        barrier()
+        if rank == 0:
+            g = gathereds[(counter[0] - 1) % nbuf]
+            bounds = [sharding.channel_range(r, world, C) for r in range(world)]
+            result["gather_check"] = {
+                "finite": bool(torch.isfinite(g).all().item()),
+                "blocks_with_audio": int(sum(bool((g[a:b].abs().amax() > 1e-3).item()) for a, b in bounds if b > a)),
+                "blocks": int(sum(1 for a, b in bounds if b > a)),
+                "own_block_equal": bool(torch.equal(g[lo:hi], audios[(counter[0] - 1) % nbuf])),
+            }
 
     if args.pcie and world == 1:
         # Host-fed variant through the package's ingest component: the wideband buffer
