@@ -53,7 +53,7 @@ class Tuner(Injector):
         self._shard = None         # (first, count) declared by shard()
         self._loaded_size = None
         self._win_size = None      # length of the reference's cached window (set by the first run)
-        self._batched = None       # (key, demod handle) of run_all
+        self._batched = {}         # (kind, C, B, A, tau, chunk) -> demod handle of run_all / run_each
 
     @property
     def input_frequency(self) -> float:
@@ -181,21 +181,62 @@ class Tuner(Injector):
         """
         handle = self._ready()
         demods = [ch.demodulator for ch in self._bounds]
-        kinds = {type(d).__name__ for d in demods}
-        geo = {(d._input_size, d._output_size, d._tau) for d in demods}
-        if len(kinds) != 1 or len(geo) != 1 or next(iter(kinds)) not in _KINDS:
+        geo = {self._geometry(d) for d in demods}
+        if len(geo) != 1 or None in geo:
             raise ValueError("run_all needs one demodulator class and geometry for all channels")
-        kind = _KINDS[next(iter(kinds))]
-        B, A, tau = next(iter(geo))
-        C = len(demods)
-        key = (kind, C, B, A, tau, chunk)
-        if self._batched is None or self._batched[0] != key:
-            h = ctypes.c_void_p()
-            hip.check(self._lib.rcfm_demod_create(kind, C, B, A, tau, int(chunk), ctypes.byref(h)))
-            self._batched = (key, hip.Handle(h, self._lib.rcfm_demod_destroy))
+        kind, B, A, tau = next(iter(geo))
         ch = 2 if kind == hip.RCFM_WBFM else 1
-        first, count = self._shard if self._shard is not None else (0, C)
+        first, count = self._shard if self._shard is not None else (0, len(demods))
         audio = hip.empty((count, A, ch), self._torch.float32)
-        hip.check(self._lib.rcfm_pipeline_run(handle, self._batched[1].value, first, count, hip.ptr(audio),
-                                              hip.stream()))
+        hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, chunk), first, count,
+                                              hip.ptr(audio), hip.stream()))
         return self._result(audio, self._cuda and not numpy_output)
+
+    def run_each(self, numpy_output: bool = True):
+        """What the reference's loop collects (examples/multi_fm_server.py:100-106,
+        ``[ch.demodulator.run(tuner.run(ch.index)) for ch in tuner.channels()]``): a list with one audio array per
+        channel, shaped as the reference's demodulators return it: [A, 1] for FM / MFM, [1, A, 2] for WBFM (wbfm.py:94 dstack) -- the shapes of FM.run / MFM.run / WBFM.run here.
+
+        The channels may differ in demodulator class, bandwidth and audio rate (broadcast stations next to
+        narrow-band ones): consecutive channels of one class and geometry run as one batched sequence, and the
+        de-emphasis state is the tuner's, per channel, as in ``run_all``.  After ``shard(first, count)`` the list
+        covers that range only.
+        """
+        handle = self._ready()
+        first, count = self._shard if self._shard is not None else (0, len(self._bounds))
+        out = []
+        i = first
+        while i < first + count:
+            g = self._geometry(self._bounds[i].demodulator)
+            if g is None:
+                raise ValueError("run_each needs an FM, MFM or WBFM demodulator on every channel")
+            j = i + 1
+            while j < first + count and self._geometry(self._bounds[j].demodulator) == g and \
+                    int(self._bounds[j].bandwidth) == int(self._bounds[i].bandwidth):
+                j += 1
+            kind, B, A, tau = g
+            ch = 2 if kind == hip.RCFM_WBFM else 1
+            audio = hip.empty((j - i, A, ch), self._torch.float32)
+            hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, 0), i, j - i,
+                                                  hip.ptr(audio), hip.stream()))
+            block = self._result(audio, self._cuda and not numpy_output)
+            out.extend(block[k:k + 1] if ch == 2 else block[k] for k in range(j - i))
+            i = j
+        return out
+
+    @staticmethod
+    def _geometry(demod):
+        kind = _KINDS.get(type(demod).__name__)
+        if kind is None:
+            return None
+        return kind, demod._input_size, demod._output_size, demod._tau
+
+    def _batched_demod(self, kind, B, A, tau, chunk):
+        # one handle per geometry, sized for all channels: rcfm_pipeline_run addresses the channels of tuner and
+        # demodulator by the same index, so the per-channel state survives regrouping
+        key = (kind, len(self._bounds), B, A, tau, int(chunk))
+        if key not in self._batched:
+            h = ctypes.c_void_p()
+            hip.check(self._lib.rcfm_demod_create(kind, len(self._bounds), B, A, tau, int(chunk), ctypes.byref(h)))
+            self._batched[key] = hip.Handle(h, self._lib.rcfm_demod_destroy)
+        return self._batched[key].value

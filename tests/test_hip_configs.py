@@ -237,3 +237,44 @@ def test_run_all_on_an_untidy_band(rc, oracle, kind):
                 assert np.all(np.isfinite(audio[c.index]))
                 continue
             assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index, rel_err(audio[c.index], want))
+
+
+def test_run_each_on_a_mixed_band(rc, oracle):
+    """The reference's loop accepts any mix of channels (examples/multi_fm_server.py:100-106 just calls each
+    channel's demodulator): broadcast WBFM next to narrow MFM / FM channels of other bandwidths and audio rates, the
+    same geometry appearing in two separate groups, an odd-sized group (a lone member in its last pair).
+    Tuner.run_each() must return what that loop returns, for two buffers (de-emphasis state per channel index)."""
+    N = 2_400_000
+    plan = [("WBFM", -900_000, 120000, 24000), ("WBFM", -700_000, 120000, 24000),
+            ("MFM", -500_000, 60000, 12000), ("MFM", -400_000, 60000, 12000),
+            ("FM", -300_000, 30000, 6000), ("FM", -250_000, 30000, 6000), ("FM", -200_000, 30000, 6000),
+            ("WBFM", 100_000, 120000, 24000), ("MFM", 400_000, 60000, 8000), ("FM", 900_000, 60000, 12000)]
+    f0 = 100_000_000
+    tuner, ref = rc.Tuner(), oracle.Tuner()
+    for kind, off, B, A in plan:
+        tuner.add_channel(f0 + off, B, getattr(rc, kind)(B, A))
+        ref.add_channel(f0 + off, B, getattr(oracle, kind)(B, A))
+    tuner.request_bandwidth(float(N))
+    ref.request_bandwidth(float(N))
+    assert tuner.input_frequency == ref.input_frequency
+    with pytest.raises(ValueError, match="one demodulator class and geometry"):
+        tuner.load(np.zeros(N, np.complex64))
+        tuner.run_all()
+    Xw = np.zeros(N, np.complex128)
+    for i, (kind, off, B, A) in enumerate(plan):
+        dev = 75e3 * B / 240000.0 if kind == "WBFM" else 0.15 * B
+        s = workloads.station_iq(30 + i, B, deviation=dev, stereo=(kind == "WBFM"))
+        kk = np.fft.fftfreq(B, 1.0 / B).astype(np.int64)
+        np.add.at(Xw, (kk + int(f0 + off - ref.input_frequency)) % N, np.fft.fft(s) * (0.3 * N / B))
+    rng = np.random.default_rng(5)
+    x = (np.fft.ifft(Xw) + 0.003 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+    for buf in range(2):
+        xb = np.roll(x, 2468 * buf)
+        tuner.load(xb)
+        ref.load(xb)
+        got = tuner.run_each()
+        assert len(got) == len(plan)
+        for c in ref.channels():
+            want = np.asarray(c.demodulator.run(ref.run_pruned(c.index)))
+            assert got[c.index].shape == want.shape, (c.index, got[c.index].shape, want.shape)
+            assert rel_err(got[c.index], want) <= TOL, (buf, c.index, plan[c.index])
