@@ -101,8 +101,9 @@ int rcfm_tuner_destroy(rcfm_tuner_t t);
 
 /* C independent channels (or C consecutive buffers of distinct channels) of
  * identical geometry B -> A.  tau = deemphasis rate (mfm.py:32, wbfm.py:35).
- * chunk = channels processed per pass through the kernel chain (0 = default, 1024 at B = 240 000):
- * bounds the workspace (about 9.6 MB per channel of a 240 kHz WBFM chunk). */
+ * chunk = channels processed per pass through the kernel chain (0 = default: 1024 at B = 240 000, proportionally
+ * more for narrower channels up to 8192, i.e. the same workspace): bounds the workspace (about 9.6 MB per channel of
+ * a 240 kHz WBFM chunk). */
 int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm_demod_t* out);
 /* FM.run / MFM.run / WBFM.run on channels [first, first+count):
  * iq [count][B] complex64 -> audio [count][A][ch] float32. */
