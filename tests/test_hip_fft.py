@@ -86,6 +86,30 @@ def test_engine_vs_rocfft_full_wideband(n):
     assert abs(e_f - e_t) <= 1e-5 * e_t
 
 
+def test_engine_vs_rocfft_four_passes_at_a_billion_points():
+    """N = 10^9 (a 1 GSPS one-second buffer, 8 GB): no three-pass plan exists, the engine runs four passes with
+    32-bit point offsets close to their range.  Compared with rocFFT in slices (24 GB of device memory in all)."""
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    n = 1_000_000_000
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.view_as_complex(torch.randn(n, 2, generator=g, device="cuda"))
+    a = torch.empty_like(x)
+    b = torch.empty_like(x)
+    hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(x), hip.ptr(a), hip.stream()))
+    hip.check(lib.rcfm_fft_c2c_rocfft(n, 1, 0, hip.ptr(x), hip.ptr(b), hip.stream()))
+    torch.cuda.synchronize()
+    del x
+    err = peak = 0.0
+    for lo in range(0, n, 1 << 26):
+        err = max(err, float(torch.max(torch.abs(a[lo:lo + (1 << 26)] - b[lo:lo + (1 << 26)]))))
+        peak = max(peak, float(torch.max(torch.abs(b[lo:lo + (1 << 26)]))))
+    del a, b
+    torch.cuda.empty_cache()
+    assert err <= 2e-5 * peak, (err, peak)
+
+
 @pytest.mark.parametrize("n,plan", [(384000, "640,600"), (375000, "600,625"), (400000, "625,640")])
 def test_big_tiles_in_both_roles(n, plan, monkeypatch):
     """The 600 / 625 / 640-point tiles (two 1024-thread workgroups per CU, twiddles as powers of one global table
