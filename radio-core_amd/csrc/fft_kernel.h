@@ -536,6 +536,16 @@ __device__ __forceinline__ void dft_p(float2* v) {
     if constexpr (R > 10 || R == 7 || R == 9) dft_nat<R>(v);
 }
 
+// RCFM_ABLATE (timing experiments only, wrong results): 1 = no inter-pass twiddle, 2 = no stage twiddles, 4 = no
+// butterflies (any kernel), 8 = no arctangent in StorePhase, 16 = no taps in the pilot stage's FIR.
+#ifndef RCFM_ABLATE
+#define RCFM_ABLATE 0
+#endif
+template <int R>
+__device__ __forceinline__ void dft_pa(float2* v) {
+    if constexpr (!(RCFM_ABLATE & 4)) dft_p<R>(v);
+}
+
 // RCFM_FFT_ROWS_PITCH17 (default): rows-type tiles use a padded pitch of 17 points instead of the XOR
 // swizzle: constant LDS offsets instead of integer work per access; the transposing store stays
 // conflict-free (34-dword stride), 32-lane reads pay one extra LDS cycle.  Measured +1.4 % on cfg4
@@ -583,8 +593,9 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
             if constexpr (GTW) pw[0] = tw[kp * step];   // issued ahead of the LDS reads it will meet
 #pragma unroll
             for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<SWZ, P17>(base + q * m, w)];
-            dft_p<R>(v);
-            if constexpr (GTW) {
+            dft_pa<R>(v);
+            if constexpr (RCFM_ABLATE & 2) {
+            } else if constexpr (GTW) {
                 twiddle_powers<R>(pw[0], pw);
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], pw[q]);
@@ -784,8 +795,9 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
                     else if constexpr (CTX) x[q] = load.post(id, b + q * m0, x[q], ctx);
                     else x[q] = load.post(id, b + q * m0, x[q]);
                 }
-                dft_p<R0>(x);
-                if constexpr (BIG) {
+                dft_pa<R0>(x);
+                if constexpr (RCFM_ABLATE & 2) {
+                } else if constexpr (BIG) {
                     float2 pw[R0];
                     twiddle_powers<R0>(tw[b], pw);
 #pragma unroll
@@ -816,7 +828,8 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
     // then successive powers of D = W_n^(f L / RL) (RL - 1 <= 9 multiplications).
     const unsigned f = (unsigned)(id.o1 * p.tw_o1 + id.o2 * p.tw_o2 + (int64_t)(i0 + w) * p.tw_i);
     float2 D = make_float2(1.f, 0.f);
-    if constexpr (!ROWS) D = big_twiddle(d, f * (unsigned)(L / RL));
+    constexpr bool PTW = !ROWS && !(RCFM_ABLATE & 1);
+    if constexpr (PTW) D = big_twiddle(d, f * (unsigned)(L / RL));
     id.i = i0 + w;
     const bool lane_ok = w < wvalid;
 #pragma unroll
@@ -826,16 +839,16 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
             float2 x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<ROWS, !BIG>(g * RL + q, w)];
-            dft_p<RL>(x);
+            dft_pa<RL>(x);
             const int kb = kbase(g);
             float2 Tw = make_float2(1.f, 0.f);
-            if constexpr (!ROWS) Tw = big_twiddle(d, f * (unsigned)kb);
+            if constexpr (PTW) Tw = big_twiddle(d, f * (unsigned)kb);
             if (lane_ok) {
 #pragma unroll
                 for (int q = 0; q < RL; ++q) {
                     const int k = kb + (L / RL) * q;
                     float2 y = x[dft_slot<RL>(q)];
-                    if constexpr (!ROWS) {
+                    if constexpr (PTW) {
                         y = cmul(y, Tw);
                         Tw = cmul(Tw, D);
                     }
@@ -960,7 +973,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
         if ((rowsL % RG == 0) || g < rowsL) {
 #pragma unroll
             for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_p<RL>(&xr[it * RL]);
+            dft_pa<RL>(&xr[it * RL]);
         }
     }
     lds_barrier();   // every slot has been read
@@ -1000,7 +1013,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
             float2 x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_p<RL>(x);
+            dft_pa<RL>(x);
             const int kb = kbase(g);
             float2 Tw = big_twiddle(d2, f * (unsigned)kb);
             if (lane_ok) {
@@ -1141,7 +1154,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
             float2 x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_p<RL>(x);
+            dft_pa<RL>(x);
 #pragma unroll
             for (int q = 0; q < RL; ++q)
                 u0[it * RL + q] = mid.first(x[dft_slot<RL>(q)], a0[it * RL + q], keep[it * RL + q]);
@@ -1182,7 +1195,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
                 float2 x[RL];
 #pragma unroll
                 for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-                dft_p<RL>(x);
+                dft_pa<RL>(x);
                 const int kb = kbase(g);
                 float2 Tw = big_twiddle(d2, f * (unsigned)kb);
                 if (lane_ok) {
@@ -1328,7 +1341,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
         if ((rowsL % RG == 0) || g < rowsL) {
 #pragma unroll
             for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_p<RL>(&xr[it * RL]);
+            dft_pa<RL>(&xr[it * RL]);
         }
     }
     lds_barrier();   // every slot has been read
@@ -1386,7 +1399,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
         float2 x[Q1];
 #pragma unroll
         for (int q = 0; q < Q1; ++q) x[q] = tile[lds_slot<true>(rg * Q1 + q, w)];
-        dft_p<Q1>(x);
+        dft_pa<Q1>(x);
         const float2 D = big_twiddle(d2, f * (unsigned)(L2 / Q1));
         float2 Tw = big_twiddle(d2, f * (unsigned)rg);
         if (w < wvalid) {

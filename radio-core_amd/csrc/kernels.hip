@@ -7,6 +7,12 @@
 // scipy calls) is derived in DESIGN.md and pinned by tests/test_oracle_scipy.py.
 
 #include "kernels.h"
+// RCFM_ABLATE & 16 (timing experiments only, wrong results; fft_kernel.h lists the bits): no taps in the pilot FIR
+#ifdef RCFM_ABLATE
+#define RCFM_ABLATE_K RCFM_ABLATE
+#else
+#define RCFM_ABLATE_K 0
+#endif
 #include "device_math.h"
 
 namespace rcfm {
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
 #pragma unroll
         for (int i = 0; i < PER / 2; ++i) acc[2 * i + 1].x = taps.pair[0].x * we[i].y;   // t = 0 of odd r
 #pragma unroll
-        for (int j = 0; j <= H; ++j) {
+        for (int j = 0; j <= ((RCFM_ABLATE_K & 16) ? 0 : H); ++j) {
             const v2f tp = taps.pair[j];
 #pragma unroll
             for (int i = 0; i < PER / 2; ++i) pk_fma_s(acc[2 * i], tp, we[i]);          // pairs j + i
