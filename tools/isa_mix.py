@@ -10,8 +10,11 @@ import sys
 def main():
     path, key = sys.argv[1], sys.argv[2]
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().endswith((":", ")")) or
-                 (l.startswith("_Z") and key in l and ": " in l))
+    start = next((i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and (l.rstrip().endswith((":", ")")) or ": " in l)),
+                 None)
+    if start is None:
+        names = sorted({l.split(":")[0] for l in lines if l.startswith("_Z") and l.rstrip().endswith(":")})
+        sys.exit("no kernel label contains %r; %d labels, e.g.\n  %s" % (key, len(names), "\n  ".join(names[:8])))
     mix = collections.Counter()
     waits = collections.Counter()
     ops = collections.Counter()
