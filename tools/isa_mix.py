@@ -13,7 +13,7 @@ def main():
     start = next((i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and (l.rstrip().endswith((":", ")")) or ": " in l)),
                  None)
     if start is None:
-        names = sorted({l.split(":")[0] for l in lines if l.startswith("_Z") and l.rstrip().endswith(":")})
+        names = sorted({l.split(":")[0][:100] for l in lines if l.startswith("_Z") and ":" in l})
         sys.exit("no kernel label contains %r; %d labels, e.g.\n  %s" % (key, len(names), "\n  ".join(names[:8])))
     mix = collections.Counter()
     waits = collections.Counter()
