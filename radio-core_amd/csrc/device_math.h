@@ -12,16 +12,17 @@ __device__ __forceinline__ float atan2_over_pi(float y, float x) {
     const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
     const float a = mn * __builtin_amdgcn_rcpf(mx);
     const float t = a * a;
-    float p = 0.002479950897395611f;
-    p = fmaf(p, t, -0.014499950222671032f);
-    p = fmaf(p, t, 0.039953526109457016f);
-    p = fmaf(p, t, -0.0725083202123642f);
-    p = fmaf(p, t, 0.10507379472255707f);
-    p = fmaf(p, t, -0.14163753390312195f);
-    p = fmaf(p, t, 0.19986307621002197f);
-    p = fmaf(p, t, -0.3333262503147125f);
-    p = fmaf(p, t, 0.9999998807907104f);
-    float r = (p * a) * 0.31830988618379067154f;   // [0, 1/4]
+    // the polynomial's coefficients carry the 1 / pi (max error 3.7e-8 in units of pi against 4.2e-8 with a final multiply)
+    float p = 0.0007893929141573608f;
+    p = fmaf(p, t, -0.0046154772862792015f);
+    p = fmaf(p, t, 0.012717602774500847f);
+    p = fmaf(p, t, -0.023080114275217056f);
+    p = fmaf(p, t, 0.03344602882862091f);
+    p = fmaf(p, t, -0.045084625482559204f);
+    p = fmaf(p, t, 0.06361839175224304f);
+    p = fmaf(p, t, -0.10610104352235794f);
+    p = fmaf(p, t, 0.31830984354019165f);
+    float r = p * a;                                // [0, 1/4]
     r = (ay > ax) ? 0.5f - r : r;                  // [0, 1/2]
     r = (x < 0.f) ? 1.f - r : r;                   // [0, 1]
     return copysignf(r, y);

@@ -48,8 +48,43 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 #endif
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// RCFM_CADD_MODE: 0 = left to the compiler (which packs some of these into v_pk_add_f32 and pays for the operand
+// pairs with v_mov), 1 = always one v_pk_add_f32 on aligned register pairs, 2 = always two scalar adds.
+#ifndef RCFM_CADD_MODE
+#define RCFM_CADD_MODE 1   // cfg4 7.368 -> 7.332 ms (five alternations on one box); the tuner's last pass loses 69 of 819 scalar VALU instructions
+#endif
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) {
+#if RCFM_CADD_MODE == 1
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f A, B, D;
+    A.x = a.x; A.y = a.y; B.x = b.x; B.y = b.y;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(D) : "v"(A), "v"(B));
+    return make_float2(D.x, D.y);
+#elif RCFM_CADD_MODE == 2
+    float x, y;
+    asm("v_add_f32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
+    asm("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
+    return make_float2(x, y);
+#else
+    return make_float2(a.x + b.x, a.y + b.y);
+#endif
+}
+__device__ __forceinline__ float2 csub(float2 a, float2 b) {
+#if RCFM_CADD_MODE == 1
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f A, B, D;
+    A.x = a.x; A.y = a.y; B.x = b.x; B.y = b.y;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(D) : "v"(A), "v"(B));
+    return make_float2(D.x, D.y);
+#elif RCFM_CADD_MODE == 2
+    float x, y;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
+    return make_float2(x, y);
+#else
+    return make_float2(a.x - b.x, a.y - b.y);
+#endif
+}
 // multiply by -i / +i
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }
