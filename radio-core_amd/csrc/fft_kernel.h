@@ -1387,6 +1387,10 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
             const int kb = kbase(g);
 #pragma unroll
             for (int q = 0; q < RL; ++q) {
+                // kb < L / RL: the rows k = kb + (L / RL) q of this q lie in [(L/RL) q, (L/RL)(q + 1)); when that range
+                // misses both kept bands and the Nyquist row, nothing of it survives the decimation -- decided at
+                // compile time (q is unrolled), so the select, the LDS write and the butterfly's unused outputs go
+                if ((L / RL) * q > L2 / 2 && (L / RL) * (q + 1) <= L - L2 / 2) continue;
                 const int k = kb + (L / RL) * q;
                 // row of the short spectrum: positive frequencies, negative frequencies, the negative
                 // Nyquist row (kept by every line), the positive one (parked in row L2: only bin A/2 of
