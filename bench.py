@@ -33,6 +33,7 @@ for p in (ROOT, os.path.join(ROOT, "radio-core_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import provenance  # noqa: E402
 from workloads_device import synth_wideband_on_device  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table (spec); 6.29e12 measured copy ceiling
@@ -122,6 +123,27 @@ def _cpu_channel(i):
     return int(i), time.perf_counter() - t0, out
 
 
+def host_memory_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def fair_workers(requested, per_worker_gb=10.0):
+    """Worker processes of the parallel CPU baseline: half the logical cores (one per physical core of an SMT-2
+    host), capped by memory -- each worker rolls and windows the whole N-point spectrum like the reference
+    (~8 GB live at N = 2.4e8) -- unless --cpu-workers asks for a number."""
+    if requested > 0:
+        return requested
+    cores = max(1, (os.cpu_count() or 2) // 2)
+    mem = host_memory_gb()
+    return max(1, min(cores, int(mem // per_worker_gb))) if mem else min(cores, 8)
+
+
 def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan, workers):
     """The oracle (a numpy port of the reference's CPU path) timed on this box's host cores, on a bounded
     sample: one Tuner.load of the full buffer + `nchan` channels of Tuner.run + demod.
@@ -153,14 +175,14 @@ def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan, workers):
     t_single = t_load + C * float(np.mean(t_ch))
     info = {
         "value": N / t_single / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-        "cpu": cpu_model(), "logical_cores": os.cpu_count(),
+        "cpu": cpu_model(), "logical_cores": os.cpu_count(), "host_mem_available_GB": round(host_memory_gb() or 0.0, 1),
         "sample": "oracle Tuner.load on the full %d-sample buffer (%.1f s) + %d of %d channels of "
                   "Tuner.run+%s.run (mean %.2f s each), extrapolated t_load + C*t_channel = %.0f s per buffer"
                   % (N, t_load, nchan, C, kind, float(np.mean(t_ch)), t_single),
     }
     if workers > 1:
         try:
-            per_worker = 2
+            per_worker = 2 if workers <= 16 else 1
             todo = [sample[j % len(sample)] for j in range(workers * per_worker)]
             with mp.get_context("fork").Pool(workers) as pool:
                 t0 = time.perf_counter()
@@ -170,6 +192,8 @@ def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan, workers):
             t_fair = t_load + C / rate
             info["fair"] = {
                 "value": N / t_fair / 1e6, "unit": "Msamples/s", "cores": workers,
+                "pool": "min(logical cores // 2 = %d, MemAvailable // 10 GB = %s)" % (
+                    max(1, (os.cpu_count() or 2) // 2), int((host_memory_gb() or 0) // 10)),
                 "sample": "same load + %d channel runs on %d worker processes in %.1f s (%.2f channels/s), "
                           "extrapolated t_load + C/rate = %.0f s per buffer" % (len(todo), workers, wall, rate, t_fair),
             }
@@ -179,7 +203,39 @@ def cpu_baseline(x_host, f_in, centres, N, C, B, A, kind, nchan, workers):
     return outputs, info
 
 
-def measure_config(name, lib, hip, steps, warmup, chunk=0):
+def measure_surface(name, x, centres, steps, warmup, abi_seconds):
+    """The same K steps through the class surface the north star names -- radiocore.tools.Tuner(cuda=True).load(x) +
+    run_all(numpy_output=False) on a device tensor, one demodulator object per channel as in
+    examples/multi_fm_server.py:127-133 -- instead of the raw ABI calls the headline times.  The steady state of that
+    surface does no per-channel Python work (tests/test_tuner_bookkeeping.py), so the two must agree."""
+    import radiocore as rc
+    N, C, B, A, raster, kind = CONFIGS[name]
+    t0 = time.perf_counter()
+    tuner = rc.Tuner(cuda=True)
+    cls = getattr(rc, kind)
+    for f in centres:
+        tuner.add_channel(f, B, cls(B, A, cuda=True))
+    tuner.request_bandwidth(float(N))
+    setup = time.perf_counter() - t0
+    for _ in range(max(warmup, 1)):
+        tuner.load(x)
+        audio = tuner.run_all(numpy_output=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tuner.load(x)
+        audio = tuner.run_all(numpy_output=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"ms_per_step": round(dt * 1e3, 4), "steps": steps, "vs_abi": round(dt / abi_seconds, 4),
+           "setup_s": round(setup, 3), "output_shape": list(audio.shape),
+           "call": "Tuner(cuda=True).load(device tensor) + run_all(numpy_output=False), %d %s demodulator objects" % (C, kind)}
+    del tuner, audio
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
     """One extra configuration on this GPU (cfg3 / cfg5; cfg4 is the headline): K timed steps of
     rcfm_tuner_load + rcfm_pipeline_run, input resident in HBM, same accounting as the headline."""
     N, C, B, A, raster, kind = CONFIGS[name]
@@ -208,10 +264,14 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0):
     finite = bool(torch.isfinite(audio).all())
     hip.check(lib.rcfm_demod_destroy(demod))
     hip.check(lib.rcfm_tuner_destroy(tuner))
-    del x, audio
+    del audio
+    torch.cuda.empty_cache()
+    surface = measure_surface(name, x, centres, steps, warmup, dt) if with_surface else None
+    del x
     torch.cuda.empty_cache()
     alg = path_bytes(N, C, B, A, kind)
     return {
+        "surface": surface,
         "workload": "%s: %d-channel Tuner at %d MSPS -> %d x %s (%d -> %d Hz)" % (name, C, N // 1_000_000, C, kind, B, A),
         "ms_per_step": round(dt * 1e3, 4), "value": round(N / dt / 1e6, 1), "unit": "Msamples/s", "steps": steps,
         "path_algorithmic_GB": round(alg / 1e9, 3), "path_hbm_frac": round(alg / dt / HBM_PEAK, 4),
@@ -272,6 +332,44 @@ def measure_batched_cfg2(lib, hip, steps, warmup, T=1024):
     }
 
 
+def measure_cfg2_single(reps=200):
+    """BASELINE configs[1] as stated: ONE 240 kSPS WBFM channel on one GPU, one call per one-second buffer (the
+    reference harness shape, tests/benchmark.py:29-31,85), device tensor in and out.  13.4 MB of algorithmic traffic
+    spread over ten dependent launches: this is launch / tile latency, not bandwidth.  Two figures: `latency_us` with
+    a synchronisation after every call (what a caller that needs the audio sees), `pipelined_us` with the calls
+    queued back to back (what a stream of buffers costs)."""
+    import radiocore as rc
+    import workloads
+    B, A = 240_000, 48_000
+    out = {"workload": "cfg2 single: one WBFM.run per call, 240000 -> 48000, device in/out"}
+    for kind in ("WBFM", "MFM", "FM"):
+        d = getattr(rc, kind)(B, A, cuda=True)
+        x = torch.from_numpy(workloads.single_channel(B, i=0, stereo=(kind == "WBFM"))).cuda()
+        for _ in range(5):
+            y = d.run(x, numpy_output=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = d.run(x, numpy_output=False)
+            torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = d.run(x, numpy_output=False)
+        torch.cuda.synchronize()
+        pipe = (time.perf_counter() - t0) / reps
+        ch = 2 if kind == "WBFM" else 1
+        per = {"FM": 8 * B + 12 * A, "MFM": 8 * B + 20 * A, "WBFM": 48 * B + 40 * A}[kind]
+        out[kind] = {"latency_us": round(lat * 1e6, 1), "pipelined_us": round(pipe * 1e6, 1),
+                     "value": round(B / pipe / 1e6, 1), "unit": "Msamples/s",
+                     "path_hbm_frac": round(per / pipe / HBM_PEAK, 5), "finite": bool(torch.isfinite(y).all()),
+                     "shape": list(y.shape)}
+        assert tuple(y.shape) == ((1, A, 2) if ch == 2 else (A, 1))
+        del d, x, y
+    out["parity"] = "tests/test_hip_parity.py::test_golden_wbfm, test_golden_mfm, test_golden_fm (240000 -> 48000)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,9 +378,10 @@ def main():
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--chunk", type=int, default=0, help="channels per pass (0 = library default)")
     ap.add_argument("--cpu-channels", type=int, default=8, help="channels in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-workers", type=int, default=8,
-                    help="worker processes of the parallel ('fair') CPU baseline (each holds ~8 GB while it rolls "
-                         "and windows the 240M-point spectrum; 0 or 1 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="worker processes of the parallel ('fair') CPU baseline; 0 = size the pool from the host: "
+                         "min(logical cores // 2, MemAvailable // 10 GB) -- each worker holds ~8 GB while it rolls "
+                         "and windows the 240M-point spectrum; 1 = skip")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other GPU configurations (cfg3, cfg5, batched cfg2) reported beside the headline")
     ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr")
@@ -298,7 +397,11 @@ def main():
     backend = os.environ.get("RCFM_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("RCFM_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
-    if world > 1:
+    # RCFM_BENCH_FORCE_DIST=1 (tests/test_nccl_world1.py): a ONE-rank launch goes down the N > 1 code path -- RCCL
+    # process group, asynchronous double-buffered gather into views of the result, barrier, max-over-ranks -- which a
+    # one-GPU box can execute (a one-rank communicator is legal) although it cannot execute N > 1 itself.
+    multi = world > 1 or os.environ.get("RCFM_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -330,10 +433,10 @@ def main():
     hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
     # N > 1: the audio blocks are double-buffered so that the gather of buffer i (RCCL's own stream, xGMI)
     # overlaps the kernels of buffer i+1; every gather completes inside the timed region (barrier()).
-    nbuf = 2 if world > 1 else 1
+    nbuf = 2 if multi else 1
     audios = [torch.empty((mine, A, ch), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     audio = audios[0]
-    gathereds = [torch.empty((C, A, ch), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+    gathereds = [torch.empty((C, A, ch), dtype=torch.float32, device="cuda") if (multi and rank == 0) else None
                  for _ in range(nbuf)]
     in_flight = [None] * nbuf
     counter = [0]
@@ -348,9 +451,9 @@ def main():
         hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
         # pipeline_run addresses channels of tuner and demod by the same index
         hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audios[slot]), s))
-        if world > 1 and backend == "nccl":  # RCCL over xGMI: the only collective on the path
+        if multi and backend == "nccl":     # RCCL over xGMI: the only collective on the path
             in_flight[slot] = sharding.gather_audio(audios[slot], C, dst=0, out=gathereds[slot], async_op=True)
-        elif world > 1:                     # dry run: same protocol through host memory
+        elif multi:                         # dry run: same protocol through host memory
             got = sharding.gather_audio(audios[slot].cpu(), C, dst=0)
             if rank == 0:
                 gathereds[slot].copy_(got)
@@ -361,7 +464,7 @@ def main():
                 in_flight[i].wait()
                 in_flight[i] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -398,7 +501,7 @@ def main():
     dom = read_profile(lib)[dominant]
     lib.rcfm_profile_enable(ctypes.c_uint64(0))
 
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -413,18 +516,13 @@ def main():
     total_alg = 16.0 * N + mine * (path_bytes(N, C, B, A, kind) - 16.0 * N) / C
     total_read = 8.0 * N + mine * (path_read_bytes(N, C, B, A, kind) - 8.0 * N) / C
 
-    # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (FETCH_SIZE x its
-    # gfx950 correction + WRITE_SIZE, collected separately; profiles/r01_e_pmc_hbm_traffic.txt)
-    traffic, traffic_source = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
-            entry = json.load(fh).get(dominant)
-        # the committed PMC passes describe cfg4 with the default chunking on one GPU: nothing else is claimed
-        if entry and args.config == "cfg4" and world == 1 and args.chunk == 0:
-            traffic = float(entry["hbm_bytes_per_launch"])
-            traffic_source = entry.get("source")
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    # HBM traffic of the dominant stage from the committed rocprofv3 PMC passes (tools/profile_traffic.sh ->
+    # tools/traffic_summary.py -> profiles/hbm_traffic.json).  The table is stamped with a digest of the kernel
+    # sources it was collected on (provenance.py): counters of other device code are withheld, not quoted.
+    traffic, traffic_source, traffic_stale = None, None, False
+    # the committed PMC passes describe cfg4 with the default chunking on one GPU: nothing else is claimed
+    if args.config == "cfg4" and world == 1 and args.chunk == 0:
+        traffic, traffic_source, traffic_stale = provenance.stage_traffic(dominant)
 
     result = {
         "metric": "IQ Msamples/s through Tuner+%s at %d channels" % (kind, C),
@@ -450,16 +548,18 @@ def main():
         "path_hbm_frac_read": round(total_read / (ms_per_step * 1e-3) / HBM_PEAK, 4),
         "path_algorithmic_GB": round(total_alg / 1e9, 3),
         "path_algorithmic_read_GB": round(total_read / 1e9, 3),
+        "kernel_source_sha": provenance.kernel_source_sha(),
         "roofline": {
             "bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_stale": traffic_stale,
+            "traffic_source": traffic_source,
             "launch_us": round(per_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": alg_bytes,
             "share_of_step": round(dom[1] / args.steps / ms_per_step, 3),
         },
     }
 
-    if world > 1:
+    if multi:
         # Channel sharding scales the per-channel stages; the replicated wideband FFT does not.
         # Per-channel-stage rate of this run = channel samples through (step time - this rank's FFT time), and the
         # Amdahl bound of the end-to-end speed-up at this world size from the single-GPU shares.
@@ -526,7 +626,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_channels > 0:
         x_host = x.cpu().numpy()
         ref_audio, result["cpu_baseline"] = cpu_baseline(x_host, f_in, centres, N, C, B, A, kind,
-                                                         args.cpu_channels, args.cpu_workers)
+                                                         args.cpu_channels, fair_workers(args.cpu_workers))
         del x_host
         # full-size parity spot check (outside the timed region): first-buffer state on
         # both sides, the oracle's sampled channels against the GPU's
@@ -546,17 +646,22 @@ def main():
     hip.check(lib.rcfm_tuner_destroy(tuner))
     if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras:
         # the other GPU configurations of BASELINE.json on the same box, outside the headline's timed region
+        surface4 = measure_surface("cfg4", x, centres, args.steps, args.warmup, ms_per_step * 1e-3)
         del x, audios, audio
         torch.cuda.empty_cache()
         result["other_configs"] = {
             "cfg3": measure_config("cfg3", lib, hip, 50, 5),
             "cfg5": measure_config("cfg5", lib, hip, 20, 3),
             "cfg2_batched": measure_batched_cfg2(lib, hip, 10, 2),
+            "cfg2_single": measure_cfg2_single(),
             "cfg1_cpu": measure_cfg1_cpu(),
         }
+        # the class surface (Tuner.load + Tuner.run_all) against the raw ABI calls of the timed region
+        result["surface"] = {"cfg4": surface4, "cfg5": result["other_configs"]["cfg5"].pop("surface"),
+                             "cfg3": result["other_configs"]["cfg3"].pop("surface")}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

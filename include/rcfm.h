@@ -117,6 +117,14 @@ int rcfm_demod_set_state(rcfm_demod_t d, const float* state_host, void* stream);
 /* Design outputs for parity checks: 51 de-emphasis taps, 41 pilot band-pass taps
  * (host, float32).  Either pointer may be NULL. */
 int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_host);
+/* One de-emphasis state per channel, whoever runs it: makes the one-channel handle `single` (the demodulator object
+ * a Channel carries, tuner.py:24) keep its state in slot `index` of `batched` (the handle rcfm_pipeline_run uses for
+ * all channels) from now on; what `single` has carried so far is moved into the slot.  Afterwards a caller may mix
+ * `demodulator.run(tuner.run(i))` (multi_fm_server.py:101-102) and the batched call across buffers and get the
+ * reference's results: there, the state lives in the demodulator object (deemphasis.py:48-49,64) and nowhere else.
+ * `single` may itself hold several channels (slots [index, index + its C) are taken: two batched handles of one
+ * geometry then share one state).  Same class, audio rate and time constant required; FM has no state (no-op). */
+int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, void* stream);
 int rcfm_demod_destroy(rcfm_demod_t d);
 
 /* Whole hot path for one wideband buffer already loaded with rcfm_tuner_load:
@@ -136,13 +144,17 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
  *                         pinned allocation) into the next free slot; RCFM_ERR_STATE when all slots are in flight
  *   acquire(stream, &p)   make `stream` wait for the oldest submitted copy; p = its device slot (pass it to
  *                         rcfm_tuner_load on the same stream)
- *   release(stream)       the work queued on `stream` so far is the last reader of that slot                */
+ *   release(stream)       the work queued on `stream` so far is the last reader of that slot
+ *   copied(&count)        how many submitted buffers have LANDED in their slot (host-side query, no wait): source
+ *                         buffers [0, count) may be reused or freed by the producer (the RingBuffer's read pointer
+ *                         may pass them, ringbuffer.py:129-160)                                              */
 int rcfm_host_register(void* host, size_t bytes);
 int rcfm_host_unregister(void* host);
 int rcfm_feeder_create(size_t bytes, int depth, void* const* device_slots, rcfm_feeder_t* out);
 int rcfm_feeder_submit(rcfm_feeder_t f, const void* src_host);
 int rcfm_feeder_acquire(rcfm_feeder_t f, void* stream, void** dptr);
 int rcfm_feeder_release(rcfm_feeder_t f, void* stream);
+int rcfm_feeder_copied(rcfm_feeder_t f, uint64_t* count);
 int rcfm_feeder_destroy(rcfm_feeder_t f);
 
 /* ---- multi-GPU: the audio gather (the publish step, examples/multi_fm_server.py:103-106) ---------- */

@@ -341,6 +341,9 @@ struct rcfm_tuner_s {
     // theta != nullptr (phase_capable bands only): angle(x) / pi goes to theta [count][B] float32, out is unused.
     // First pass length n_1 of the band's inverse FFT (0 without an engine): its last pass stores rows of n_1 samples.
     int band_row_length(int first) { return phase_capable(first) ? (int)band(bw[first]).engine->row_length() : 0; }
+    // Padded phase rows (fused_tuner_ifft's theta_pitch) need the last pass to write rows of n_1 samples with no
+    // outer line index, i.e. a TWO-pass plan (B <= 262144); three-pass bands keep contiguous phases.
+    bool band_two_pass(int first) { return phase_capable(first) && band(bw[first]).engine->npass() == 2; }
 
     void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr, int theta_pitch = 0) {
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
@@ -387,7 +390,14 @@ struct rcfm_demod_s {
     float zi_h[50];
     float pilot_h[41];
     float pilot_g_h[41];   // zero-phase kernel g = b (*) reverse(b), centre first
-    DeviceBuffer taps, pilot_g, state;
+    DeviceBuffer taps, pilot_g;
+    // De-emphasis state, [C][ch][50].  Normally this handle's own buffer; after rcfm_demod_bind_state a
+    // one-channel handle's state IS slot `index` of a batched handle's buffer (shared ownership), so the
+    // per-channel caller and the batched caller carry ONE state per channel like the reference's
+    // Deemphasis._state (deemphasis.py:48-49,64).
+    std::shared_ptr<DeviceBuffer> state_buf = std::make_shared<DeviceBuffer>();
+    size_t state_off = 0;   // floats into state_buf
+    float* state_ptr() const { return state_buf->as<float>() + state_off; }
     float side_tap = 0.23f;
     ResampleGeom geom;   // B -> A, real, Hamming
     PlanCache r2c_B, c2c_inv_B, c2c_fwd_B, c2c_inv_A, c2r_A;
@@ -455,7 +465,7 @@ struct rcfm_demod_s {
         if (kind == RCFM_FM) return;
         std::vector<float> all((size_t)C * ch * 50);
         for (size_t i = 0; i < all.size(); ++i) all[i] = zi_h[i % 50];
-        RC_HIP(hipMemcpyAsync(state.get(), all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        RC_HIP(hipMemcpyAsync(state_ptr(), all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice, s));
         RC_HIP(hipStreamSynchronize(s));
     }
 
@@ -584,7 +594,7 @@ struct rcfm_demod_s {
                         fused_fft_decim_ifft(*eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
                                              buf_dc.as<float2>(), s, pitch);
                     }
-                    float* st = state.as<float>() + (size_t)first * ch * 50;
+                    float* st = state_ptr() + (size_t)first * ch * 50;
                     run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true,
                                pitch ? (int)eng_Ad->row_length() : 0, pitch);
                     return;
@@ -608,7 +618,7 @@ struct rcfm_demod_s {
                                              geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
                     // -> [cnt][A][2] float32, L/R interleaved
                 }
-                float* st = state.as<float>() + (size_t)first * ch * 50;
+                float* st = state_ptr() + (size_t)first * ch * 50;
                 run_deemph(reinterpret_cast<float*>(V), audio, st, cnt, s, true);
                 return;
             }
@@ -644,7 +654,7 @@ struct rcfm_demod_s {
                 pf[3]->exec(V, V, work.get(), s);   // -> [cnt][A][2] float32, L/R interleaved
             }
             // wbfm.py:90-100  de-emphasis (separate L/R state), joint DC removal, clip
-            float* st = state.as<float>() + (size_t)first * ch * 50;
+            float* st = state_ptr() + (size_t)first * ch * 50;
             {
                 StageTimer tm(ST_DEEMPH, s);
                 launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
@@ -686,7 +696,7 @@ struct rcfm_demod_s {
                                            geom.wr.as<float>(), geom.scale, buf_dc.as<float2>(), s);
             }
             if (kind == RCFM_FM) return;
-            float* st = state.as<float>() + (size_t)first * 50;
+            float* st = state_ptr() + (size_t)first * 50;
             run_deemph(dst, audio, st, cnt, s, true);
             return;
         }
@@ -713,7 +723,7 @@ struct rcfm_demod_s {
                 fused_ifft_real_out(*eng_A, Yfull, dst, buf_TA.as<float2>(), cnt, 1.0f, s);
             }
             if (kind == RCFM_FM) return;
-            float* st = state.as<float>() + (size_t)first * 50;
+            float* st = state_ptr() + (size_t)first * 50;
             run_deemph(dst, audio, st, cnt, s, true);
             return;
         }
@@ -742,7 +752,7 @@ struct rcfm_demod_s {
             f2.exec(Y, v, work.get(), s);
         }
         // mfm.py:63-65
-        float* st = state.as<float>() + (size_t)first * 50;
+        float* st = state_ptr() + (size_t)first * 50;
         {
             StageTimer tm(ST_DEEMPH, s);
             launch_fir(v, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
@@ -790,9 +800,16 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // a copy some other component of this process already mapped (PyTorch's ProcessGroupNCCL loads
+        // torch/lib/librccl.so, SONAME librccl.so.1) is reused: two RCCL instances in one process would each
+        // own a set of communicators and IPC handles
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
             if (r.lib) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) return;
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
@@ -828,6 +845,7 @@ struct rcfm_feeder_s {
     std::vector<hipEvent_t> ready, done;   // ready: the copy into the slot has landed; done: its consumer has finished
     hipStream_t copy = nullptr;
     uint64_t head = 0, tail = 0;           // submitted / released buffers
+    uint64_t landed = 0;                   // buffers whose copy is known to have completed (rcfm_feeder_copied)
     ~rcfm_feeder_s() {
         if (copy) (void)hipStreamSynchronize(copy);
         for (auto e : ready) (void)hipEventDestroy(e);
@@ -1030,7 +1048,7 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
         if (kind != RCFM_FM) {
             deemphasis_design(A, tau, d->taps_h, d->zi_h);
             d->taps.upload(d->taps_h, sizeof(d->taps_h));
-            d->state.reset((size_t)C * d->ch * 50 * sizeof(float));
+            d->state_buf->reset((size_t)C * d->ch * 50 * sizeof(float));
             d->reset_state(nullptr);
         }
         d->alloc();
@@ -1063,7 +1081,7 @@ int rcfm_demod_get_state(rcfm_demod_t d, float* state_host, void* stream) {
     return guarded([&] {
         RC_REQUIRE(d && state_host, RCFM_ERR_ARG, "NULL argument");
         if (d->kind == RCFM_FM) return;
-        RC_HIP(hipMemcpyAsync(state_host, d->state.get(), (size_t)d->C * d->ch * 50 * sizeof(float),
+        RC_HIP(hipMemcpyAsync(state_host, d->state_ptr(), (size_t)d->C * d->ch * 50 * sizeof(float),
                               hipMemcpyDeviceToHost, as_stream(stream)));
         RC_HIP(hipStreamSynchronize(as_stream(stream)));
     });
@@ -1073,9 +1091,29 @@ int rcfm_demod_set_state(rcfm_demod_t d, const float* state_host, void* stream) 
     return guarded([&] {
         RC_REQUIRE(d && state_host, RCFM_ERR_ARG, "NULL argument");
         if (d->kind == RCFM_FM) return;
-        RC_HIP(hipMemcpyAsync(d->state.get(), state_host, (size_t)d->C * d->ch * 50 * sizeof(float),
+        RC_HIP(hipMemcpyAsync(d->state_ptr(), state_host, (size_t)d->C * d->ch * 50 * sizeof(float),
                               hipMemcpyHostToDevice, as_stream(stream)));
         RC_HIP(hipStreamSynchronize(as_stream(stream)));
+    });
+}
+
+int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(single && batched, RCFM_ERR_ARG, "NULL handle");
+        RC_REQUIRE(single != batched && single->kind == batched->kind && single->A == batched->A &&
+                       single->tau == batched->tau,
+                   RCFM_ERR_ARG, "bind_state needs demodulators of one class, audio rate and time constant");
+        RC_REQUIRE(index >= 0 && index + single->C <= batched->C, RCFM_ERR_INDEX, "channel index out of range");
+        if (single->kind == RCFM_FM) return;   // fm.py carries no state
+        const size_t per = (size_t)single->C * single->ch * 50;
+        const size_t slot = batched->state_off + (size_t)index * single->ch * 50;
+        float* dst = batched->state_buf->as<float>() + slot;
+        if (single->state_buf == batched->state_buf && single->state_off == slot) return;   // already bound to this slot
+        // the history this demodulator has carried so far moves into the slot (stream-ordered)
+        RC_HIP(hipMemcpyAsync(dst, single->state_ptr(), per * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+        RC_HIP(hipStreamSynchronize(as_stream(stream)));   // the old buffer may be freed right below
+        single->state_buf = batched->state_buf;
+        single->state_off = slot;
     });
 }
 
@@ -1118,8 +1156,8 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                     const char* e = std::getenv("RCFM_PHASE_PITCH");
                     return e && e[0] == '0';
                 }();
-                if (!no_pad && d->kind != RCFM_WBFM && d->eng_B && n1 > 0 && n1 % 16 != 0 && d->B % n1 == 0 &&
-                    d->B < (1 << 20) && n1 < (1 << 12)) {
+                if (!no_pad && d->kind != RCFM_WBFM && d->eng_B && t->band_two_pass(first + off) && n1 > 0 &&
+                    n1 % 16 != 0 && d->B % n1 == 0 && d->B < (1 << 20) && n1 < (1 << 12)) {
                     rows.row = n1;
                     rows.pitch = (n1 + 15) / 16 * 16;     // floats: a 64-byte store segment never straddles a line
                     d->buf_iq.reserve((size_t)d->chunk * rows.channel_stride(d->B) * sizeof(float));
@@ -1202,6 +1240,22 @@ int rcfm_feeder_release(rcfm_feeder_t f, void* stream) {
         const int i = (int)(f->tail % (uint64_t)f->depth);
         RC_HIP(hipEventRecord(f->done[i], as_stream(stream)));
         f->tail += 1;
+    });
+}
+
+int rcfm_feeder_copied(rcfm_feeder_t f, uint64_t* count) {
+    return guarded([&] {
+        RC_REQUIRE(f && count, RCFM_ERR_ARG, "NULL argument");
+        // Copies complete in submission order (one copy stream).  ready[i] always refers to the LATEST copy into
+        // slot i; when buffer k's slot has been re-submitted since, that newer copy ran behind k on the same stream,
+        // so "the newer copy is complete" still implies "k has landed", and "not ready" merely answers conservatively.
+        while (f->landed < f->head) {
+            const hipError_t e = hipEventQuery(f->ready[(size_t)(f->landed % (uint64_t)f->depth)]);
+            if (e == hipErrorNotReady) break;
+            RC_HIP(e);
+            f->landed += 1;
+        }
+        *count = f->landed;
     });
 }
 
@@ -1332,18 +1386,32 @@ extern "C++" {
 namespace {
 // Device copies of filter taps, keyed by their values: Bandpass / Deemphasis hand the same host array to every call
 // (bandpass.py:72, deemphasis.py:64), so after the first call nothing is allocated, uploaded or waited for.
-const float* cached_taps(const std::vector<float>& taps) {
+// The caller holds a shared_ptr across its launch: an eviction on another thread cannot free taps a kernel is about
+// to be launched with (the buffer dies when the last holder lets go; hipFree then orders itself behind the launch).
+// At most 64 sets are kept, least recently used out first, one per miss.
+std::shared_ptr<DeviceBuffer> cached_taps(const std::vector<float>& taps) {
+    struct Entry {
+        std::shared_ptr<DeviceBuffer> buf;
+        uint64_t used;
+    };
     static std::mutex mu;
-    static std::map<std::vector<float>, std::unique_ptr<DeviceBuffer>> cache;
+    static std::map<std::vector<float>, Entry> cache;
+    static uint64_t tick = 0;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(taps);
     if (it == cache.end()) {
-        if (cache.size() >= 64) cache.clear();   // (buffers of launches still in flight are freed stream-ordered by hipFree)
-        auto buf = std::make_unique<DeviceBuffer>();
+        if (cache.size() >= 64) {
+            auto oldest = cache.begin();
+            for (auto e = cache.begin(); e != cache.end(); ++e)
+                if (e->second.used < oldest->second.used) oldest = e;
+            cache.erase(oldest);
+        }
+        auto buf = std::make_shared<DeviceBuffer>();
         buf->upload(taps.data(), taps.size() * sizeof(float));
-        it = cache.emplace(taps, std::move(buf)).first;
+        it = cache.emplace(taps, Entry{std::move(buf), 0}).first;
     }
-    return it->second->as<float>();
+    it->second.used = ++tick;
+    return it->second.buf;
 }
 }  // namespace
 }  // extern "C++"
@@ -1356,9 +1424,9 @@ int rcfm_filtfilt(int C, int n, const float* taps_host, int ntaps, const void* x
                    "The length of the input vector x must be greater than padlen, which is " +
                        std::to_string(3 * ntaps) + ".");
         hipStream_t s = as_stream(stream);
-        const float* gd = cached_taps(zero_phase_kernel(taps_host, ntaps));
-        launch_pilot_stage(nullptr, static_cast<const float*>(x), nullptr, static_cast<float*>(y), n, C, gd,
-                           ntaps - 1, 0.f, s);
+        const std::shared_ptr<DeviceBuffer> gd = cached_taps(zero_phase_kernel(taps_host, ntaps));
+        launch_pilot_stage(nullptr, static_cast<const float*>(x), nullptr, static_cast<float*>(y), n, C,
+                           gd->as<float>(), ntaps - 1, 0.f, s);
     });
 }
 
@@ -1368,26 +1436,41 @@ int rcfm_lfilter_fir(int C, int n, const float* taps_host, int ntaps, void* stat
         RC_REQUIRE(taps_host && x && y && (state || ntaps < 2), RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(C >= 1 && n >= 1 && ntaps >= 1, RCFM_ERR_ARG, "bad lfilter size");
         hipStream_t s = as_stream(stream);
-        const float* td = cached_taps(std::vector<float>(taps_host, taps_host + ntaps));
-        launch_fir(static_cast<const float*>(x), static_cast<float*>(y), n, 1, C, td, ntaps,
+        const std::shared_ptr<DeviceBuffer> td = cached_taps(std::vector<float>(taps_host, taps_host + ntaps));
+        launch_fir(static_cast<const float*>(x), static_cast<float*>(y), n, 1, C, td->as<float>(), ntaps,
                    static_cast<const float*>(state), nullptr, s);
-        launch_fir_state(static_cast<const float*>(x), n, 1, C, td, ntaps, static_cast<float*>(state), s);
+        launch_fir_state(static_cast<const float*>(x), n, 1, C, td->as<float>(), ntaps, static_cast<float*>(state), s);
     });
 }
 
 extern "C++" {
 namespace {
-// Plans and workspaces of rcfm_hilbert, keyed by (n, C): PLL.step (pll.py:25-34) is called once per buffer with the
-// same geometry, so nothing is planned, allocated or synchronised after the first call.
+// Plans and workspaces of rcfm_hilbert: PLL.step (pll.py:25-34) is called once per buffer with the same geometry,
+// so nothing is planned, allocated or synchronised after the first call.  The key includes the device and the
+// STREAM: calls on one stream are ordered by that stream and may share spec / tmp; two PLLs on different streams
+// (or threads) get separate workspaces instead of racing on one.  At most 16 entries are kept, least recently
+// used out first (hipFree waits for the device, so an evicted workspace is never freed under a running kernel).
 struct HilbertPlan {
     std::unique_ptr<FftEngine> eng;            // engine lengths: real -> full spectrum -> masked inverse transform
     std::unique_ptr<FftPlan> fwd, inv;         // otherwise rocFFT (r2c, mask kernel, c2c inverse)
     DeviceBuffer spec, tmp, work;
+    uint64_t used = 0;
 };
-HilbertPlan& hilbert_plan(int n, int C) {
-    static std::map<std::pair<int, int>, std::unique_ptr<HilbertPlan>> plans;
-    auto it = plans.find({n, C});
+using HilbertKey = std::tuple<int, hipStream_t, int, int>;   // device, stream, n, C
+HilbertPlan& hilbert_plan(int n, int C, hipStream_t s) {
+    static std::map<HilbertKey, std::unique_ptr<HilbertPlan>> plans;
+    static uint64_t tick = 0;
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    const HilbertKey key{dev, s, n, C};
+    auto it = plans.find(key);
     if (it == plans.end()) {
+        if (plans.size() >= 16) {
+            auto oldest = plans.begin();
+            for (auto e = plans.begin(); e != plans.end(); ++e)
+                if (e->second->used < oldest->second->used) oldest = e;
+            plans.erase(oldest);
+        }
         auto p = std::make_unique<HilbertPlan>();
         FftPlanDesc probe;
         if (use_engine() && fft_plan_describe(n, &probe)) {
@@ -1400,8 +1483,9 @@ HilbertPlan& hilbert_plan(int n, int C) {
             p->spec.reset((size_t)C * (n / 2 + 1) * sizeof(float2));
             p->work.reserve(std::max(p->fwd->work_bytes(), p->inv->work_bytes()));
         }
-        it = plans.emplace(std::make_pair(n, C), std::move(p)).first;
+        it = plans.emplace(key, std::move(p)).first;
     }
+    it->second->used = ++tick;
     return *it->second;
 }
 std::mutex g_hilbert_mu;
@@ -1413,8 +1497,8 @@ int rcfm_hilbert(int C, int n, const void* x, void* z, void* stream) {
         RC_REQUIRE(x && z, RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(C >= 1 && n >= 1, RCFM_ERR_ARG, "bad hilbert size");
         hipStream_t s = as_stream(stream);
-        std::lock_guard<std::mutex> lock(g_hilbert_mu);
-        HilbertPlan& p = hilbert_plan(n, C);
+        std::lock_guard<std::mutex> lock(g_hilbert_mu);   // the cache itself; the kernels are ordered by their stream
+        HilbertPlan& p = hilbert_plan(n, C, s);
         if (p.eng) {
             fused_real_fft(*p.eng, static_cast<const float*>(x), p.spec.as<float2>(), p.tmp.as<float2>(), C,
                            kKeepLowerHalf /* bins above n/2 are never read */, s);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rcfm_demod_get_state": [_vp, _fp, _vp],
     "rcfm_demod_set_state": [_vp, _fp, _vp],
     "rcfm_demod_get_taps": [_vp, _fp, _fp],
+    "rcfm_demod_bind_state": [_vp, _vp, _i, _vp],
     "rcfm_demod_destroy": [_vp],
     "rcfm_pipeline_run": [_vp, _vp, _i, _i, _vp, _vp],
     "rcfm_host_register": [_vp, _sz],
@@ -59,6 +60,7 @@ SIGNATURES = {
     "rcfm_feeder_submit": [_vp, _vp],
     "rcfm_feeder_acquire": [_vp, _vp, ctypes.POINTER(_vp)],
     "rcfm_feeder_release": [_vp, _vp],
+    "rcfm_feeder_copied": [_vp, ctypes.POINTER(ctypes.c_uint64)],
     "rcfm_feeder_destroy": [_vp],
     "rcfm_comm_unique_id": [_vp],
     "rcfm_comm_init_rank": [_i, _i, _vp, ctypes.POINTER(_vp)],

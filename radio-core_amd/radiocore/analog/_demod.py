@@ -1,6 +1,7 @@
 """Shared plumbing of FM / MFM / WBFM: one librcfm demodulator handle per instance."""
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -24,11 +25,47 @@ class Demodulator(Injector):
         self._output_size = int(output_size)
         self._tau = float(deemphasis)
         self._batch = int(batch)
+        self._chunk = int(chunk)
         super().__init__(cuda)
-        h = ctypes.c_void_p()
-        hip.check(self._lib.rcfm_demod_create(self._KIND, self._batch, self._input_size, self._output_size,
-                                              self._tau, int(chunk), ctypes.byref(h)))
-        self._handle = hip.Handle(h, self._lib.rcfm_demod_destroy)
+        # what rcfm_demod_create would refuse is refused here, at construction like the reference's constructors
+        # (bandpass.py:50-52 designs the pilot filter in __init__) ...
+        if self._batch < 1 or self._input_size < 2 or self._output_size < 1:
+            raise ValueError("bad demodulator size")
+        if self._KIND == hip.RCFM_WBFM:
+            if (19e3 + 50) / (0.5 * self._input_size) >= 1.0:
+                raise ValueError("Invalid cutoff frequency: frequencies must be greater than 0 and less than fs/2.")
+            if self._input_size <= 3 * 41:
+                raise ValueError("The length of the input vector x must be greater than padlen, which is 123.")
+        # ... but the librcfm handle (plans, tables, workspaces: ~12 MB for a 240 kHz WBFM channel) is created on first
+        # use: a Tuner with thousands of channels that only ever calls run_all() never needs the per-channel handles
+        self._h = None
+        self._binding = None       # (weakref to the batched hip.Handle, channel index): Tuner._bind_states
+
+    @property
+    def _handle(self):
+        if self._h is None:
+            h = ctypes.c_void_p()
+            hip.check(self._lib.rcfm_demod_create(self._KIND, self._batch, self._input_size, self._output_size,
+                                                  self._tau, self._chunk, ctypes.byref(h)))
+            self._h = hip.Handle(h, self._lib.rcfm_demod_destroy)
+            self._apply_binding()
+        return self._h
+
+    def _bind(self, batched_handle, index):
+        """Keep this demodulator's de-emphasis state in slot `index` of a Tuner's batched handle from now on
+        (rcfm_demod_bind_state: one state per channel, whoever runs it -- deemphasis.py:48-49,64)."""
+        self._binding = (weakref.ref(batched_handle), int(index))
+        if self._h is not None:
+            self._apply_binding()
+
+    def _apply_binding(self):
+        if self._binding is None:
+            return
+        owner = self._binding[0]()
+        if owner is None or not owner.value:      # the tuner is gone: the state is this object's own again
+            self._binding = None
+            return
+        hip.check(self._lib.rcfm_demod_bind_state(self._h.value, owner.value, self._binding[1], hip.stream()))
 
     @property
     def channels(self):

@@ -43,7 +43,8 @@ class Feeder(Injector):
         hip.check(self._lib.rcfm_feeder_create(self._size * self._dtype.itemsize, len(self._slots), ptrs,
                                                ctypes.byref(h)))
         self._handle = hip.Handle(h, self._lib.rcfm_feeder_destroy)
-        self._sources = []          # host arrays whose copies are still in flight (kept alive)
+        self._sources = []          # host arrays whose copies have not landed yet (kept alive)
+        self._dropped = 0           # submitted buffers already dropped from _sources
 
     @property
     def depth(self):
@@ -70,5 +71,32 @@ class Feeder(Injector):
             yield slot
         finally:
             hip.check(self._lib.rcfm_feeder_release(self._handle.value, hip.stream()))
-            if len(self._sources) > self.depth:
-                del self._sources[0]
+            self._drop_landed()
+
+    def _drop_landed(self):
+        # A source array is let go only once its H2D copy is known to have completed (rcfm_feeder_copied, a
+        # host-side event query): the host may run far ahead of the GPU, and a temporary handed to submit()
+        # (an ascontiguousarray copy, a slice nobody else holds) must outlive its DMA.
+        n = ctypes.c_uint64()
+        hip.check(self._lib.rcfm_feeder_copied(self._handle.value, ctypes.byref(n)))
+        k = int(n.value) - self._dropped
+        if k > 0:
+            del self._sources[:k]
+            self._dropped += k
+
+    def close(self):
+        """Destroy the feeder: waits for the copy stream, THEN lets go of the device slots (they are torch
+        tensors: returning them to the caching allocator before the last copy has run would hand memory under a
+        pending DMA to the next allocation) and of the host arrays."""
+        if self._handle is not None and self._handle.value:
+            status = self._lib.rcfm_feeder_destroy(self._handle.value)   # synchronises the copy stream
+            self._handle.value = None
+            hip.check(status)
+        self._slots = []
+        self._sources = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:               # interpreter shutdown
+            pass

@@ -54,8 +54,9 @@ def gather_audio(local, channels, dst=0, group=None, out=None, async_op=False):
     """
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return GatherHandle(None, lambda: local) if async_op else local
+    # (a one-rank group runs the collective like any other: that is how a one-GPU box exercises the RCCL path)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = channel_counts(world, channels)

@@ -54,6 +54,15 @@ class Tuner(Injector):
         self._loaded_size = None
         self._win_size = None      # length of the reference's cached window (set by the first run)
         self._batched = {}         # (kind, C, B, A, tau, chunk) -> demod handle of run_all / run_each
+        # Everything below is derived from the channel list and rebuilt only when add_channel / reset change it
+        # (`_version`): load / run / run_all do no per-channel Python work in the steady state.
+        self._version = 0
+        self._lo = self._hi = self._bw_sum = None     # running min / max / sum of _recalculate
+        self._abi_arrays = None    # (version, rolls, bws) as ctypes arrays
+        self._plan = None          # (version, shard) -> run_all / run_each launch plan
+        self._uniform = (None, None)   # (version, the one geometry all channels share or None)
+        self._state_owner = {}     # (kind, C, B, A, tau) -> the batched handle whose buffer holds that geometry's state
+        self._bound_version = {}   # batched key -> channel-list version its demodulators were bound at
 
     @property
     def input_frequency(self) -> float:
@@ -78,42 +87,58 @@ class Tuner(Injector):
 
     def add_channel(self, frequency: float, bandwidth: float, demodulator):
         """Register a channel; recalculates the input geometry."""
-        self._bounds.append(Channel(
+        ch = Channel(
             index=len(self._bounds),
             bandwidth=bandwidth,
             demodulator=demodulator,
             lower_frequency=(frequency - (bandwidth / 2)),
             center_frequency=frequency,
             higher_frequency=(frequency + (bandwidth / 2)),
-        ))
-        self._recalculate()
+        )
+        self._bounds.append(ch)
+        self._recalculate(ch)
 
     def reset(self):
         """Forget all channels (raises ValueError like the reference: min() of nothing)."""
         self._bounds = []
+        self._lo = self._hi = self._bw_sum = None
         self._recalculate()
 
-    def _recalculate(self):
-        # tuner.py:163-174
-        lower = min([ch.lower_frequency for ch in self._bounds])
-        higher = max([ch.higher_frequency for ch in self._bounds])
+    def _recalculate(self, added=None):
+        # tuner.py:163-174.  The reference recomputes min / max / sum over every channel on each add_channel (O(C^2)
+        # to set up C channels: 2.9 s for 8192); the running forms below give the same floats -- min and max are
+        # exact, and Python's sum() adds left to right exactly like the running total -- in O(1) per channel.
+        self._version += 1
+        if added is not None and self._lo is not None:
+            self._lo = min(self._lo, added.lower_frequency)
+            self._hi = max(self._hi, added.higher_frequency)
+            self._bw_sum = self._bw_sum + added.bandwidth
+        else:
+            self._lo = min([ch.lower_frequency for ch in self._bounds])
+            self._hi = max([ch.higher_frequency for ch in self._bounds])
+            self._bw_sum = sum([ch.bandwidth for ch in self._bounds])
+        lower, higher = self._lo, self._hi
         self._input_frequency = (lower + higher) / 2
         self._input_bandwidth = (higher - lower)
-        mean_bandwidth = sum([ch.bandwidth for ch in self._bounds])
+        mean_bandwidth = self._bw_sum
         mean_bandwidth //= len(self._bounds)
         self._input_bandwidth += (self._input_bandwidth * -1) % mean_bandwidth
 
     # ---- device side ---------------------------------------------------------
 
     def _device_tuner(self, n):
-        rolls = [int(self._input_frequency - ch.center_frequency) for ch in self._bounds]
-        bws = [int(ch.bandwidth) for ch in self._bounds]
-        key = (n, tuple(rolls), tuple(bws))
+        # rolls depend on the channel list only (input_frequency is recomputed by add_channel, never by
+        # request_bandwidth): the handle is keyed by (n, _version) and the O(C) lists are built once per version
+        key = (n, self._version)
         if key != self._handle_key:
-            roll_a = (ctypes.c_int64 * len(rolls))(*rolls)
-            bw_a = (ctypes.c_int32 * len(bws))(*bws)
+            if self._abi_arrays is None or self._abi_arrays[0] != self._version:
+                rolls = [int(self._input_frequency - ch.center_frequency) for ch in self._bounds]
+                bws = [int(ch.bandwidth) for ch in self._bounds]
+                self._abi_arrays = (self._version, (ctypes.c_int64 * len(rolls))(*rolls),
+                                    (ctypes.c_int32 * len(bws))(*bws))
+            _, roll_a, bw_a = self._abi_arrays
             h = ctypes.c_void_p()
-            hip.check(self._lib.rcfm_tuner_create(n, len(rolls), roll_a, bw_a, ctypes.byref(h)))
+            hip.check(self._lib.rcfm_tuner_create(n, len(self._bounds), roll_a, bw_a, ctypes.byref(h)))
             self._handle = hip.Handle(h, self._lib.rcfm_tuner_destroy)
             self._handle_key = key
             self._loaded_size = None
@@ -168,29 +193,59 @@ class Tuner(Injector):
         hip.check(self._lib.rcfm_tuner_run(handle, first, count, hip.ptr(out), hip.stream()))
         return out
 
+    def _launch_plan(self):
+        """Groups of consecutive channels that share demodulator class, geometry and bandwidth, for the declared
+        shard: [(first, count, kind, B, A, tau)], built once per channel-list version (O(C)) -- the steady
+        state of run_all / run_each does no per-channel Python work.  Replacing ``channel.demodulator`` by hand
+        after add_channel is not seen until the next add_channel / reset / shard (the reference has no such
+        cache because it has no batched call)."""
+        key = (self._version, self._shard)
+        if self._plan is None or self._plan[0] != key:
+            first, count = self._shard if self._shard is not None else (0, len(self._bounds))
+            groups = []
+            i = first
+            while i < first + count:
+                g = self._geometry(self._bounds[i].demodulator)
+                bw = int(self._bounds[i].bandwidth)
+                j = i + 1
+                while g is not None and j < first + count and int(self._bounds[j].bandwidth) == bw and \
+                        self._geometry(self._bounds[j].demodulator) == g:
+                    j += 1
+                groups.append((i, j - i) + (g if g is not None else (None, None, None, None)))
+                i = j
+            self._plan = (key, groups, first, count)
+        return self._plan[1], self._plan[2], self._plan[3]
+
     def run_all(self, numpy_output: bool = True, chunk: int = 0):
         """Audio of every channel, [C, A, ch] float32, in channel-index order.
 
         All channels must carry demodulators of one class and geometry.  The
-        de-emphasis state of this batched path lives in the tuner (one state per
-        channel, carried from buffer to buffer) and is independent of the
-        per-channel demodulator instances.
+        de-emphasis state is ONE per channel, carried from buffer to buffer and
+        shared with the channel's demodulator object (``_bind_states``), so
+        ``ch.demodulator.run(tuner.run(i))`` and this call may alternate.
 
         After ``shard(first, count)`` only that range is run (its spectrum rows are all ``load``
         kept) and the result is [count, A, ch] -- the block sharding.gather_audio expects.
         """
         handle = self._ready()
-        demods = [ch.demodulator for ch in self._bounds]
-        geo = {self._geometry(d) for d in demods}
-        if len(geo) != 1 or None in geo:
+        _, first, count = self._launch_plan()
+        geo = self._plan_uniform()     # ALL channels of the tuner, not only the shard's
+        if geo is None:
             raise ValueError("run_all needs one demodulator class and geometry for all channels")
-        kind, B, A, tau = next(iter(geo))
+        kind, B, A, tau = geo
         ch = 2 if kind == hip.RCFM_WBFM else 1
-        first, count = self._shard if self._shard is not None else (0, len(demods))
         audio = hip.empty((count, A, ch), self._torch.float32)
         hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, chunk), first, count,
                                               hip.ptr(audio), hip.stream()))
         return self._result(audio, self._cuda and not numpy_output)
+
+    def _plan_uniform(self):
+        """(kind, B, A, tau) when every channel of the tuner carries the same demodulator class and geometry,
+        else None; cached per channel-list version."""
+        if self._uniform[0] != self._version:
+            geo = {self._geometry(c.demodulator) for c in self._bounds}
+            self._uniform = (self._version, next(iter(geo)) if len(geo) == 1 and None not in geo else None)
+        return self._uniform[1]
 
     def run_each(self, numpy_output: bool = True):
         """What the reference's loop collects (examples/multi_fm_server.py:100-106,
@@ -203,25 +258,17 @@ class Tuner(Injector):
         covers that range only.
         """
         handle = self._ready()
-        first, count = self._shard if self._shard is not None else (0, len(self._bounds))
+        groups, first, count = self._launch_plan()
         out = []
-        i = first
-        while i < first + count:
-            g = self._geometry(self._bounds[i].demodulator)
-            if g is None:
+        for i, n, kind, B, A, tau in groups:
+            if kind is None:
                 raise ValueError("run_each needs an FM, MFM or WBFM demodulator on every channel")
-            j = i + 1
-            while j < first + count and self._geometry(self._bounds[j].demodulator) == g and \
-                    int(self._bounds[j].bandwidth) == int(self._bounds[i].bandwidth):
-                j += 1
-            kind, B, A, tau = g
             ch = 2 if kind == hip.RCFM_WBFM else 1
-            audio = hip.empty((j - i, A, ch), self._torch.float32)
-            hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, 0), i, j - i,
+            audio = hip.empty((n, A, ch), self._torch.float32)
+            hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, 0), i, n,
                                                   hip.ptr(audio), hip.stream()))
             block = self._result(audio, self._cuda and not numpy_output)
-            out.extend(block[k:k + 1] if ch == 2 else block[k] for k in range(j - i))
-            i = j
+            out.extend(block[k:k + 1] if ch == 2 else block[k] for k in range(n))
         return out
 
     @staticmethod
@@ -239,4 +286,34 @@ class Tuner(Injector):
             h = ctypes.c_void_p()
             hip.check(self._lib.rcfm_demod_create(kind, len(self._bounds), B, A, tau, int(chunk), ctypes.byref(h)))
             self._batched[key] = hip.Handle(h, self._lib.rcfm_demod_destroy)
+            self._bind_states(key, self._batched[key])
+        elif self._bound_version.get(key) != self._version:
+            self._bind_states(key, self._batched[key])
         return self._batched[key].value
+
+    def _bind_states(self, key, handle):
+        """ONE de-emphasis state per channel, as in the reference, where it lives in the demodulator object the
+        Channel carries (deemphasis.py:48-49,64; wbfm.py:53-57): every channel's demodulator instance of this
+        geometry keeps its state in its channel's slot of the batched handle from now on (rcfm_demod_bind_state moves
+        what it has carried so far), and further batched handles of the same geometry (another `chunk`) share the
+        first one's buffer.  Mixing ``ch.demodulator.run(tuner.run(i))`` and ``run_all()`` across buffers then gives
+        what the reference's loop gives.  O(C) Python, once per change of the channel list; a demodulator whose own
+        librcfm handle does not exist yet (it is created on first use) binds when it does; FM carries no state."""
+        kind, C, B, A, tau, _ = key
+        self._bound_version[key] = self._version
+        if kind == hip.RCFM_FM:
+            return
+        owner_key = (kind, C, B, A, tau)
+        owner = self._state_owner.get(owner_key)
+        if owner is None:
+            self._state_owner[owner_key] = handle
+        elif owner.value != handle.value:
+            hip.check(self._lib.rcfm_demod_bind_state(handle.value, owner.value, 0, hip.stream()))
+        geo = (kind, B, A, tau)
+        seen = set()
+        for c in self._bounds:
+            d = c.demodulator
+            if id(d) in seen or self._geometry(d) != geo or getattr(d, "_batch", 0) != 1:
+                continue                      # (an object registered on two channels keeps its first slot)
+            seen.add(id(d))
+            d._bind(handle, c.index)

@@ -108,6 +108,28 @@ def test_run_all_narrowband_fm_geometry(rc, oracle):
         assert rel_err(audio[c.index], want) <= TOL, c.index
 
 
+@pytest.mark.parametrize("kind,B", [("FM", 375000), ("MFM", 337500)])
+def test_run_all_on_a_three_pass_band(rc, oracle, kind, B):
+    """Channels wider than 262 144 samples get a THREE-pass inverse FFT in the tuner (375 000 = 40 . 75 . 125,
+    337 500 = 60 . 75 . 75: first-pass lengths that are not multiples of 16).  The padded phase rows of the
+    narrow-channel path (rcfm_pipeline_run, cfg5) only exist for two-pass plans; these geometries must stay on
+    contiguous phases and agree with the reference loop (multi_fm_server.py:100-106, fm.py:60-67)."""
+    N, A, C = 1_500_000, 37500, 3
+    centres = workloads.channel_grid(C, 380000)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.4, stereo=False, deviation=0.1 * B)
+    for buf in range(2):
+        xb = np.roll(x, 313 * buf)
+        tuner.load(xb)
+        ref.load(xb)
+        audio = tuner.run_all()
+        assert audio.shape == (C, A, 1)
+        for c in ref.channels():
+            iq = ref.run_pruned(c.index)
+            want = np.asarray(c.demodulator.run(iq)).reshape(A, 1)
+            assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index, rel_err(audio[c.index], want))
+
+
 # ---- full geometries --------------------------------------------------------------------------------
 
 def _full_config(rc, oracle, name, sample, buffers=1):
@@ -237,6 +259,94 @@ def test_run_all_on_an_untidy_band(rc, oracle, kind):
                 assert np.all(np.isfinite(audio[c.index]))
                 continue
             assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index, rel_err(audio[c.index], want))
+
+
+@pytest.mark.parametrize("kind", ["MFM", "WBFM"])
+def test_off_raster_stations_through_run_all(rc, oracle, kind, monkeypatch):
+    """Stations a few hundred Hz off their channel centres (real broadcast bands are never on the tuner's raster).
+    The reference unwraps the phase in float32 (fm.py:62): at these offsets the accumulated phase reaches
+    2 pi * offset ~ 2000-4000 rad and ITS audio drifts 4e-6 .. 3e-5 of peak away from the float64 evaluation of the
+    same formulas -- still inside the 1e-4 tolerance, so parity with the reference must hold, AND the HIP path
+    (wrapped phase steps, no accumulated phase) must be the one that is closer to the float64 truth on every
+    off-raster channel.  Truth = the oracle with its discriminator replaced by arg(x[t] conj x[t-1]) / pi in
+    float64 (everything downstream then runs in float64 too).  DESIGN.md section 6 has the large-offset case."""
+    N, B, A, C = 2_400_000, 60000, 12000, 5
+    centres = workloads.channel_grid(C, 70000)
+    offsets = [310, -450, 0, 620, -170]
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    f_in = ref.input_frequency
+    Xw = np.zeros(N, np.complex128)
+    kk = np.fft.fftfreq(B, 1.0 / B).astype(np.int64)
+    for i, fc in enumerate(centres):
+        s = workloads.station_iq(40 + i, B, stereo=(kind == "WBFM"), offset=offsets[i])
+        np.add.at(Xw, (kk + int(fc - f_in)) % N, np.fft.fft(s) * (0.3 * N / B))
+    rng = np.random.default_rng(3)
+    x = (np.fft.ifft(Xw) + 0.003 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+    ch = 2 if kind == "WBFM" else 1
+    tuner.load(x)
+    ref.load(x)
+    audio = tuner.run_all()
+    iqs = [ref.run_pruned(i) for i in range(C)]
+    want_ref = [np.asarray(c.demodulator.run(iqs[c.index])).reshape(A, ch) for c in ref.channels()]
+
+    def truth_discriminator(sig):
+        z = np.asarray(sig).astype(np.complex128)
+        d = np.zeros(len(z))
+        d[1:] = np.angle(z[1:] * np.conj(z[:-1])) / np.pi
+        return d
+
+    monkeypatch.setattr(oracle, "discriminator", truth_discriminator)
+    truth = [np.asarray(getattr(oracle, kind)(B, A).run(iqs[i])).reshape(A, ch) for i in range(C)]
+    for i in range(C):
+        vs_ref, vs_truth, ref_vs_truth = rel_err(audio[i], want_ref[i]), rel_err(audio[i], truth[i]), \
+            rel_err(want_ref[i], truth[i])
+        print(kind, i, offsets[i], "hip-ref %.2e  hip-truth %.2e  ref-truth %.2e" % (vs_ref, vs_truth, ref_vs_truth))
+        assert vs_ref <= TOL, (kind, i, vs_ref)
+        assert vs_truth <= 0.1 * TOL, (kind, i, vs_truth)
+        if offsets[i]:
+            assert vs_truth < ref_vs_truth, (kind, i, vs_truth, ref_vs_truth)
+
+
+@pytest.mark.parametrize("kind", ["MFM", "WBFM"])
+def test_per_channel_and_batched_calls_share_one_state_per_channel(rc, oracle, kind):
+    """In the reference the de-emphasis state lives in the demodulator object a Channel carries
+    (deemphasis.py:48-49,64; wbfm.py:53-57), so it does not matter which caller runs a channel.  Here the batched
+    call keeps its states in one [C][ch][50] buffer and every channel's demodulator is bound to its slot
+    (rcfm_demod_bind_state): the reference's loop (multi_fm_server.py:100-106) and run_all / run_each / a second
+    batched handle (another chunk size) may alternate from buffer to buffer, and every buffer must equal what the
+    reference's loop gives for that buffer -- which depends on the state all previous buffers left."""
+    N, B, A, C = 1_200_000, 60000, 12000, 5
+    centres = workloads.channel_grid(C, 50000)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    ch = 2 if kind == "WBFM" else 1
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.35, stereo=(kind == "WBFM"))
+    # one warm-up through the per-channel caller BEFORE the batched handle exists: the history it leaves in the
+    # demodulator objects must move into the batched buffer when the binding happens
+    callers = ["loop", "all", "loop", "each", "all3", "loop", "all"]
+    for buf, how in enumerate(callers):
+        xb = np.roll(x, 1711 * buf) * np.float32(1.0 - 0.05 * buf)
+        tuner.load(xb)
+        ref.load(xb)
+        if how == "loop":
+            got = [np.asarray(c.demodulator.run(tuner.run(c.index))).reshape(A, ch) for c in tuner.channels()]
+        elif how == "each":
+            got = [np.asarray(a).reshape(A, ch) for a in tuner.run_each()]
+        else:
+            got = tuner.run_all(chunk=3 if how == "all3" else 0)
+        for c in ref.channels():
+            want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, ch)
+            assert rel_err(got[c.index], want) <= TOL, (kind, buf, how, c.index, rel_err(got[c.index], want))
+    # the state really is one: what the demodulator object reports is its slot of the batched buffer
+    one = tuner.channels()[2].demodulator.state()
+    tuner.channels()[2].demodulator.reset()
+    assert not np.array_equal(tuner.channels()[2].demodulator.state(), one)
+    tuner.load(x)
+    ref.load(x)
+    ref.channels()[2].demodulator = getattr(oracle, kind)(B, A)          # the reference's "fresh demodulator"
+    got = tuner.run_all()
+    for c in ref.channels():
+        want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, ch)
+        assert rel_err(got[c.index], want) <= TOL, (kind, "after reset", c.index)
 
 
 def test_run_each_on_a_mixed_band(rc, oracle):

@@ -389,6 +389,75 @@ def test_feeder_overlaps_copies_and_matches_synchronous_load(rc):
         feeder.submit(np.zeros(10, np.complex64))
 
 
+def test_feeder_keeps_temporaries_alive_until_their_copy_has_landed(rc):
+    """Feeder.submit() may be handed an array nobody else holds (a roll, a scaled copy): the feeder is then the only
+    owner until the DMA has run.  The host queues buffers without ever waiting for the GPU here, so dropping a source
+    when its slot is released (host-side bookkeeping) would free memory under a pending copy; sources are dropped
+    only once rcfm_feeder_copied() says their copy has completed.  (multi_fm_server.py:95-98 is the hand-over.)"""
+    import gc
+    import torch
+    N, B, A, K = 600000, 60000, 12000, 6
+    centres = [100e6, 100.1e6]
+    base = workloads.wideband(N, 100e6, centres, B, gain=0.5)
+    t = rc.Tuner()
+    for f in centres:
+        t.add_channel(f, B, rc.FM(B, A))
+    t.request_bandwidth(float(N))
+    want = []
+    for k in range(K):
+        t.load(np.roll(base, 777 * k))
+        want.append(t.run_all())
+    feeder = rc.Feeder(N, dtype=np.complex64, depth=2)
+    got = []
+    feeder.submit(np.roll(base, 0))                       # temporaries: no reference survives this statement
+    for k in range(K):
+        if k + 1 < K:
+            feeder.submit(np.roll(base, 777 * (k + 1)))
+        gc.collect()
+        with feeder.next() as x:
+            t.load(x)
+            got.append(t.run_all(numpy_output=False))      # device result: nothing here waits for the GPU
+    torch.cuda.synchronize()
+    for k in range(K):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    feeder._drop_landed()
+    assert feeder._sources == [] and feeder._dropped == K   # everything has landed: nothing is kept alive
+    feeder.submit(np.roll(base, 5))
+    feeder.close()                                          # waits for the copy stream, then frees the slots
+    assert feeder._slots == [] and feeder._sources == []
+    feeder.close()                                          # idempotent
+
+
+def test_hilbert_on_two_streams_does_not_share_a_workspace(rc, oracle):
+    """rcfm_hilbert caches plans and workspaces per (device, stream, n, C): two PLLs stepping concurrently on
+    different streams with the same geometry (pll.py:25-34) must not race on one spectrum buffer."""
+    import torch
+    n = 240000
+    rng = np.random.default_rng(11)
+    xs = [rng.standard_normal(n).astype(np.float32) for _ in range(2)]
+    want = []
+    for x in xs:
+        p = oracle.PLL()
+        p.step(x)
+        want.append(p.image(2))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    plls = [rc.PLL(cuda=True), rc.PLL(cuda=True)]
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(20):                                   # interleaved, no synchronisation in between
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                plls[i].step(dev[i])
+                outs[i] = plls[i].image(2)
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert rel_err(outs[i].cpu().numpy(), want[i]) <= 1e-3   # Im(z^2)/|z^2| of noise: conditioning, not the race
+        p = rc.PLL()
+        p.step(xs[i])
+        assert np.array_equal(outs[i].cpu().numpy(), p.image(2)), i   # bit-equal to the single-stream result
+
+
 def test_server_loop_example(rc, oracle):
     """examples/multi_fm_pipeline.py: producer thread -> RingBuffer -> Feeder -> Tuner.run_all -> wire frames, three
     seconds; every published message equals the oracle's audio for that second and channel."""

@@ -11,11 +11,16 @@ MI355X guide describes for that kernel's access shape (FETCH_SIZE tallies every 
 128-byte requests, 1.0 for 64-byte ones, 0.5 for 32-byte ones).  Write side: TCC_EA0_WRREQ_64B counts the 64-byte
 writes, the rest are 32-byte: bytes_written = 64 n64 + 32 (n - n64); WRITE_SIZE (KiB) is printed beside it.
 
---json: also writes the per-stage totals bench.py reports as roofline.traffic (kernel -> stage map below, cfg4).
+--json: also writes the per-stage totals bench.py reports as roofline.traffic (kernel -> stage map below, cfg4),
+stamped with the commit, a digest of the kernel sources (provenance.py) and the names of the profiled kernels.
 """
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import provenance  # noqa: E402
 
 STAGES = [   # (stage of rcfm_profile_*, regex on the kernel name); first match wins
     ("tuner_fft_N", r"k_fft_tile<(600|625|640),.*LoadPlainT<false>, (StorePlainT<false>|StoreRowWindow)"),
@@ -95,6 +100,11 @@ def main():
             e["hbm_bytes_per_launch"] = e["read_bytes"] + e["written_bytes"]
             e["source"] = source
             e["note"] = "sum over the stage's kernels of one launch each (one chunk of channels; the wideband FFT once per buffer)"
+        # the stamp bench.py checks: these counters describe THIS device code (run the summary in the checkout the
+        # profiled library was built from, before touching radio-core_amd/csrc again)
+        names = sorted({name for (name, _), c in data.items() if name.startswith("k_")})
+        stages["_meta"] = {"kernel_source_sha": provenance.kernel_source_sha(), "commit": provenance.git_head(),
+                           "source": source, "kernels": [n[:140] for n in names]}
         json.dump(stages, open(out_json, "w"), indent=1)
 
 
