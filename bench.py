@@ -66,6 +66,7 @@ def stage_bytes(name, N, B, A, kind):
         "deemphasis": 8 * A * ch,
         "deemph_state": 0,
         "dc_clip": 8 * A * ch,
+        "lds_chain": 24 * B + 12 * A,          # tuner gather + IFFT_B (16B) and FM (8B + 12A) in one kernel
     }
     return float(table[name])
 

@@ -119,12 +119,13 @@ int rcfm_demod_set_state(rcfm_demod_t d, const float* state_host, void* stream);
 int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_host);
 /* One de-emphasis state per channel, whoever runs it: makes the one-channel handle `single` (the demodulator object
  * a Channel carries, tuner.py:24) keep its state in slot `index` of `batched` (the handle rcfm_pipeline_run uses for
- * all channels) from now on; what `single` has carried so far is moved into the slot.  Afterwards a caller may mix
+ * all channels) from now on; move_history != 0: what `single` has carried so far is moved into the slot (it has run
+ * before), 0: the slot's content stands (`single` is new, the batched handle has the history).  Afterwards a caller may mix
  * `demodulator.run(tuner.run(i))` (multi_fm_server.py:101-102) and the batched call across buffers and get the
  * reference's results: there, the state lives in the demodulator object (deemphasis.py:48-49,64) and nowhere else.
  * `single` may itself hold several channels (slots [index, index + its C) are taken: two batched handles of one
  * geometry then share one state).  Same class, audio rate and time constant required; FM has no state (no-op). */
-int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, void* stream);
+int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, int move_history, void* stream);
 int rcfm_demod_destroy(rcfm_demod_t d);
 
 /* Whole hot path for one wideband buffer already loaded with rcfm_tuner_load:

@@ -19,6 +19,7 @@
 #include "fft_plan.h"
 #include "fused_passes.h"
 #include "kernels.h"
+#include "lds_chain.h"
 
 namespace rcfm {
 
@@ -164,13 +165,15 @@ enum Stage : int {
     ST_DEEMPH,          // W5a FIR51 + partial sums
     ST_DEEMPH_STATE,    // W5b
     ST_DC_CLIP,         // W5c
+    ST_LDS_CHAIN,       // T2 + F1 + F2 of narrow FM / MFM channels in one kernel (lds_chain.h)
     ST_COUNT
 };
 
 const char* const kStageNames[ST_COUNT] = {
     "tuner_fft_N",   "tuner_gather",  "tuner_ifft_B", "discriminator", "pilot_stage",
     "rfft_B",        "hilbert_mask",  "ifft_B",       "stereo_mix",    "fft_B",
-    "audio_spectrum", "ifft_A",       "deemphasis",   "deemph_state",  "dc_clip"};
+    "audio_spectrum", "ifft_A",       "deemphasis",   "deemph_state",  "dc_clip",
+    "lds_chain"};
 
 // One process-wide instance; handles of different threads may time stages concurrently, so every access goes
 // through `mu` (uncontended in the single-DSP-thread use the reference has).
@@ -333,6 +336,16 @@ struct rcfm_tuner_s {
             it = bands.emplace(b, std::move(nb)).first;
         }
         return *it->second;
+    }
+
+    // The fast gather's preconditions (fused_passes.hip, LoadTunerGatherFast) for the band of channel `first`: haloed
+    // spectrum with 32-bit bases, window argument small enough for the series, no up-sampling Nyquist rule.
+    bool fast_gather_ok(int first) {
+        if (first < 0 || first >= nch || halo <= 0) return false;
+        const int32_t B = bw[first];
+        const ResampleGeom& g = band(B).geom;
+        const bool series = 6.28318530717958647692 * ((double)(B / 2 + 2) / (double)n) < 0.25;
+        return series && halo >= B / 2 + 1 && g.nyq_mode != NYQ_UP && B <= n;
     }
 
     // Can run() leave angle(x) / pi instead of x for this channel's band?  (engine path only)
@@ -1097,7 +1110,7 @@ int rcfm_demod_set_state(rcfm_demod_t d, const float* state_host, void* stream) 
     });
 }
 
-int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, void* stream) {
+int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, int move_history, void* stream) {
     return guarded([&] {
         RC_REQUIRE(single && batched, RCFM_ERR_ARG, "NULL handle");
         RC_REQUIRE(single != batched && single->kind == batched->kind && single->A == batched->A &&
@@ -1109,9 +1122,11 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
         const size_t slot = batched->state_off + (size_t)index * single->ch * 50;
         float* dst = batched->state_buf->as<float>() + slot;
         if (single->state_buf == batched->state_buf && single->state_off == slot) return;   // already bound to this slot
-        // the history this demodulator has carried so far moves into the slot (stream-ordered)
-        RC_HIP(hipMemcpyAsync(dst, single->state_ptr(), per * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
-        RC_HIP(hipStreamSynchronize(as_stream(stream)));   // the old buffer may be freed right below
+        if (move_history) {
+            // the history this demodulator has carried so far moves into the slot (stream-ordered)
+            RC_HIP(hipMemcpyAsync(dst, single->state_ptr(), per * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+            RC_HIP(hipStreamSynchronize(as_stream(stream)));   // the old buffer may be freed right below
+        }
         single->state_buf = batched->state_buf;
         single->state_off = slot;
     });
@@ -1139,6 +1154,36 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
         for (int off = 0; off < count; off += d->chunk) {
             const int cnt = std::min(d->chunk, count - off);
             RC_REQUIRE(t->bw[first + off] == d->B, RCFM_ERR_SIZE, "input_sig size and input_size mismatch");
+            // Narrow FM / MFM channels whose whole chain fits the LDS of a CU: gather, IFFT_B, discriminator, FFT_B,
+            // decimation and IFFT_A of a channel pair in ONE kernel (lds_chain.h); only the audio reaches memory.
+            // RCFM_LDS_CHAIN=0: the multi-pass launches (A/B runs).
+            static const bool no_lds = [] {
+                const char* e = std::getenv("RCFM_LDS_CHAIN");
+                return e && e[0] == '0';
+            }();
+            if (!no_lds && d->kind != RCFM_WBFM && lds_chain_supported(d->B, d->A) && t->fast_gather_ok(first + off)) {
+                RC_REQUIRE(t->loaded, RCFM_ERR_STATE, "rcfm_pipeline_run called before rcfm_tuner_load");
+                RC_REQUIRE(!t->loaded_windowed || (first + off >= t->loaded_first &&
+                                                   first + off + cnt <= t->loaded_first + t->loaded_count),
+                           RCFM_ERR_STATE,
+                           "channel outside the shard the spectrum was loaded for (rcfm_tuner_shard, then rcfm_tuner_load)");
+                for (int i = 0; i < cnt; ++i)
+                    RC_REQUIRE(t->bw[first + off + i] == d->B, RCFM_ERR_SIZE, "input_sig size and input_size mismatch");
+                const ResampleGeom& tg = t->band(d->B).geom;
+                float* out_c = outp + (size_t)off * d->A;
+                float* dst = (d->kind == RCFM_FM) ? out_c : d->buf_v.as<float>();
+                LdsChainArgs a{t->spectrum(), t->base_dev.as<int32_t>() + first + off, t->n, tg.nyq,
+                               tg.nyq_mode == NYQ_DOWN ? tg.nyq - 1 : -1, d->geom.wr.as<float>(), d->geom.scale, dst,
+                               d->buf_dc.as<float2>(), cnt};
+                {
+                    StageTimer tm(ST_LDS_CHAIN, as_stream(stream));
+                    RC_REQUIRE(launch_lds_chain(d->B, d->A, a, as_stream(stream)), RCFM_ERR_RUNTIME,
+                               "LDS chain refused a geometry it lists");
+                }
+                if (d->kind == RCFM_MFM)
+                    d->run_deemph(dst, out_c, d->state_ptr() + (size_t)(first + off) * 50, cnt, as_stream(stream), true);
+                continue;
+            }
             // Every demodulator starts with the FM discriminator, which only needs the samples' phases:
             // the tuner's last pass leaves angle(x) / pi (float32) instead of x (complex64) -- half the
             // bytes written here and read back by the first demod kernel.  RCFM_PHASE_LINK=0: complex hand-over.

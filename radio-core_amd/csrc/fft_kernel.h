@@ -495,13 +495,28 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
 struct BlockPos {
     unsigned tile, batch;
 };
-__device__ __forceinline__ BlockPos block_pos() {
-    const unsigned gx = gridDim.x, x = blockIdx.x, z = blockIdx.z;
+// A workgroup's place in the launch: the hardware's blockIdx / gridDim, or -- persistent kernels -- the place a
+// virtual workgroup id would have had in the equivalent one-tile-per-workgroup launch (same linear order, so the
+// same XCD: the persistent grid is a multiple of 8 and workgroup b only ever takes ids = b mod 8).
+struct VBlock {
+    unsigned x, y, z, gx, gy, gz;
+};
+__device__ __forceinline__ VBlock vblock_hw() {
+    return VBlock{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z};
+}
+__device__ __forceinline__ VBlock vblock_of(unsigned id, unsigned gx, unsigned gy, unsigned gz) {
+    const unsigned x = id % gx, r = id / gx;
+    return VBlock{x, r % gy, r / gy, gx, gy, gz};
+}
+__device__ __forceinline__ BlockPos block_pos(const VBlock& vb);
+__device__ __forceinline__ BlockPos block_pos() { return block_pos(vblock_hw()); }
+__device__ __forceinline__ BlockPos block_pos(const VBlock& vb) {
+    const unsigned gx = vb.gx, x = vb.x, z = vb.z;
 #if RCFM_FFT_XCD_ORDER
     if (gx <= RCFM_FFT_XCD_GROUP_MAX) {
         // linear workgroup id = x + gx (y + gy z); with gy = 1 and z0 = z & ~7 its low three bits are those of
         // q = x + gx (z & 7), the position inside the group: XCD (q & 7) takes signal z0 + (q & 7), tile q >> 3
-        if (gridDim.y == 1 && (z | 7u) < gridDim.z) {
+        if (vb.gy == 1 && (z | 7u) < vb.gz) {
             const unsigned q = x + gx * (z & 7u);
             return BlockPos{q >> 3, (z & ~7u) + (q & 7u)};
         }
@@ -666,9 +681,12 @@ constexpr bool triple_tile(int L) { return RCFM_FFT_TRIPLE400 && L == 400; }
 //                   (tile_base is workgroup-uniform, off a 32-bit per-lane offset) and does NO
 //                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
 // StoreOp contract: operator()(id, k, tile_base, off, v).
-template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
+// PERSIST: the grid is two workgroups per CU and each walks tiles id = blockIdx.x, + gridDim.x, ... of the virtual grid
+// `vgrid` (RCFM_FFT_PERSIST): no workgroup dispatch between the tiles of a CU, the next tile's loads are issued right
+// behind the stores of the previous one.
+template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp, bool PERSIST = false>
 __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
-                                                                                          StoreOp store) {
+                                                                                          StoreOp store, dim3 vgrid) {
     // BIG: two 1024-thread workgroups per CU -- the tile is the whole LDS budget of the workgroup (80 KiB), so the
     // stage twiddles come from the table in global memory (twiddle_powers) and rows tiles use the XOR swizzle.
     constexpr bool BIG = big_tile_pair(L) || triple_tile(L);
@@ -683,13 +701,19 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
     __shared__ __attribute__((aligned(16))) float2 tw_lds[BIG ? 1 : L];
     const float2* tw = BIG ? d.stage_tw : tw_lds;
     const FftPass& p = d.p;
-    const int tid = threadIdx.x;
-    const int w = tid & (W - 1), rg = tid >> 4;
+    static_assert(!PERSIST || BIG, "persistent form: big tiles only (no stage-twiddle table in LDS to refill)");
 
+    const unsigned vtotal = PERSIST ? vgrid.x * vgrid.y * vgrid.z : 1u;
+#pragma unroll 1
+    for (unsigned vid = PERSIST ? blockIdx.x : 0u; vid < vtotal; vid += PERSIST ? gridDim.x : 1u) {
+    int tid = threadIdx.x;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid));   // per-thread index tables (e / L, e % L per load) stay in the loop
+    const int w = tid & (W - 1), rg = tid >> 4;
+    const VBlock vb = PERSIST ? vblock_of(vid, vgrid.x, vgrid.y, vgrid.z) : vblock_hw();
     LineId id;
-    const BlockPos bp = block_pos();
+    const BlockPos bp = block_pos(vb);
     id.batch = bp.batch;
-    const unsigned o = blockIdx.y, n_o2 = (unsigned)p.n_o2;
+    const unsigned o = vb.y, n_o2 = (unsigned)p.n_o2;
     id.o1 = n_o2 == 1 ? o : o / n_o2;
     id.o2 = n_o2 == 1 ? 0 : o - (unsigned)id.o1 * n_o2;
     const int i0 = (int)bp.tile * W;
@@ -699,7 +723,13 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + (int64_t)i0 * p.in_i;
     const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0;
-    const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
+    unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
+    if constexpr (PERSIST) {
+        // the strides are loop-invariant, and hoisting every multiple of them out of the tile loop (10 .. 20 row
+        // offsets per thread) costs more registers than the 64 a two-workgroups-per-CU kernel has: keep the
+        // address arithmetic inside the iteration
+        asm volatile("" : "+s"(in_l), "+s"(in_i), "+s"(out_k));
+    }
 
     // ---- global loads: all issued before anything waits -----------------------------------
     constexpr int NF = fetch_count<LoadOp>::value;
@@ -893,7 +923,14 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
             }
         }
     }
+    if constexpr (PERSIST) lds_barrier();   // the next tile overwrites the LDS image: every last-stage read is done
+    }   // tiles of this workgroup
 }
+
+template <class T, class = void>
+struct mid_upper_rows_zero : std::false_type {};
+template <class T>
+struct mid_upper_rows_zero<T, std::void_t<decltype(T::kUpperRowsZero)>> : std::bool_constant<T::kUpperRowsZero> {};
 
 // ---- two transforms on one tile -----------------------------------------------------
 //
@@ -1020,6 +1057,15 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
 #pragma unroll
             for (int q = 0; q < RL; ++q) {
                 const int k = kb + (L / RL) * q;
+                // A MidOp that declares kUpperRowsZero maps every row k > L / 2 to zero (one-sided spectra).  kb < L / RL,
+                // so the rows of this q start at (L / RL) q: decided at compile time, and the outputs of the last-stage
+                // butterfly that nobody reads are not computed at all (dead code in the unrolled DFT).
+                if constexpr (mid_upper_rows_zero<MidOp>::value) {
+                    if ((L / RL) * q > L / 2) {
+                        tile[lds_slot<true>(k, w)] = make_float2(0.f, 0.f);
+                        continue;
+                    }
+                }
                 float2 y = mid(id, k, xr[it * RL + dft_slot<RL>(q)], aux[it * RL + q]);
                 tile[lds_slot<true>(k, w)] = y;
             }
@@ -1618,6 +1664,39 @@ template <> struct is_plain_functor<StoreRowWindow> : std::true_type {};
 // Which pass kinds a functor pair is ever used with (prunes template instantiations).
 enum PassKinds : int { kAnyPass = 0, kStridedOnly = 1, kRowsOnly = 2 };
 
+// -DRCFM_FFT_PERSIST=1 builds the persistent form of the big / 400-point streaming passes as well (two resp. three
+// workgroups per CU walking their tiles; the environment variable RCFM_FFT_PERSIST=0 then switches back at run time).
+// Measured and NOT adopted (round 3, same-box alternation, no spills in either form): wideband FFT 2.44 vs 2.16 ms,
+// cfg4 7.46 vs 7.18 ms, cfg5 1.73 vs 1.61 ms -- workgroup dispatch between tiles is not what the passes wait for, and
+// a fixed tile list per workgroup loses the hardware's dynamic balancing.
+#ifndef RCFM_FFT_PERSIST
+#define RCFM_FFT_PERSIST 0
+#endif
+inline bool getenv_fft_persist() {
+    static const bool v = [] {
+        const char* e = std::getenv("RCFM_FFT_PERSIST");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+template <int LEN, int A, int B, int C, int D, bool ROWS, class LoadOp, class StoreOp>
+inline void launch_fft_tile_one(const FftPassDev& d, dim3 grid, const LoadOp& ld, const StoreOp& st, hipStream_t s) {
+    constexpr int T = tile_threads(LEN);
+    constexpr bool kResidentTile = big_tile_pair(LEN) || triple_tile(LEN);
+    if constexpr (RCFM_FFT_PERSIST && kResidentTile && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
+        // streaming passes of long transforms: as many workgroups as the chip holds at once, each walking its tiles
+        const unsigned resident = (unsigned)((big_tile_pair(LEN) ? 2 : 3) * FftEngine::compute_units());
+        const unsigned total = grid.x * grid.y * grid.z;
+        if (getenv_fft_persist() && resident % 8 == 0 && total > resident) {
+            hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, ROWS, T, LoadOp, StoreOp, true>), dim3(resident), dim3(T), 0, s,
+                               d, ld, st, grid);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, ROWS, T, LoadOp, StoreOp, false>), grid, dim3(T), 0, s, d, ld, st, grid);
+}
+
 template <int KIND = kAnyPass, class LoadOp, class StoreOp>
 inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, const StoreOp& st, hipStream_t s) {
     bool done = false;
@@ -1633,34 +1712,18 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
     case LEN:                                                                                                 \
         if (rows) {                                                                                           \
             if constexpr (KIND != kStridedOnly)                                                               \
-                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, true, tile_threads(LEN), LoadOp, StoreOp>), grid, \
-                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
+                launch_fft_tile_one<LEN, A, B, C, D, true, LoadOp, StoreOp>(d, grid, ld, st, s);               \
         } else {                                                                                              \
             if constexpr (KIND != kRowsOnly)                                                                  \
-                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, false, tile_threads(LEN), LoadOp, StoreOp>), grid, \
-                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
+                launch_fft_tile_one<LEN, A, B, C, D, false, LoadOp, StoreOp>(d, grid, ld, st, s);              \
         }                                                                                                     \
         done = true;                                                                                          \
         break;
             RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
-#undef RCFM_CASE
             default: break;
         }
         if constexpr (is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
             switch (d.p.L) {
-#define RCFM_CASE(LEN, A, B, C, D)                                                                            \
-    case LEN:                                                                                                 \
-        if (rows) {                                                                                           \
-            if constexpr (KIND != kStridedOnly)                                                               \
-                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, true, tile_threads(LEN), LoadOp, StoreOp>), grid, \
-                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
-        } else {                                                                                              \
-            if constexpr (KIND != kRowsOnly)                                                                  \
-                hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, false, tile_threads(LEN), LoadOp, StoreOp>), grid, \
-                                   dim3(tile_threads(LEN)), 0, s, d, ld, st);                                 \
-        }                                                                                                     \
-        done = true;                                                                                          \
-        break;
                 RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
                 default: break;

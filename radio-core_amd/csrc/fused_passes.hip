@@ -327,8 +327,12 @@ struct MidStereoMix {
 // scipy.signal.hilbert's mask as the point-wise stage between the pair FFT's last pass and the masked
 // inverse FFT's first pass (k_fft_tile2): bin = k * stride + i; the value leaves swapped and scaled for the
 // inverse transform.  No auxiliary input.
-struct MidHilbertMask {
+template <bool UPPER_ZERO>
+struct MidHilbertMaskT {
     [[maybe_unused]] static constexpr bool kAux = true;
+    // UPPER_ZERO: n = L * stride with L even, so every row k > L / 2 holds bins above n / 2 only and the mask zeroes
+    // it: the kernel then neither computes those outputs of the first transform nor calls the functor for them.
+    static constexpr bool kUpperRowsZero = UPPER_ZERO;
     int n, stride;
     float scale;
     __device__ __forceinline__ float fetch_aux(const LineId&, int, int64_t, unsigned) const { return 0.f; }
@@ -718,10 +722,14 @@ void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const 
         const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), n);
         const FftPassDev d2 = ei.pass_dev(0, n, ei.tmp_stride());
         fftk::LoadPlainT<false> ld{tmp_f};
-        MidHilbertMask mid{(int)n, (int)d1.p.out_k, (float)(1.0 / (double)n)};
         fftk::StorePlainT<false> st{tmp_i, 1.0f};
-        RC_REQUIRE(fftk::launch_fft_tile2(d1, d2, pairs, ld, mid, st, s), RCFM_ERR_RUNTIME,
-                   "two-transform tile kernel refused a pair it should accept");
+        const float scale = (float)(1.0 / (double)n);
+        bool ok;
+        if (d1.p.L % 2 == 0 && (int64_t)d1.p.L * d1.p.out_k == n)
+            ok = fftk::launch_fft_tile2(d1, d2, pairs, ld, MidHilbertMaskT<true>{(int)n, (int)d1.p.out_k, scale}, st, s);
+        else
+            ok = fftk::launch_fft_tile2(d1, d2, pairs, ld, MidHilbertMaskT<false>{(int)n, (int)d1.p.out_k, scale}, st, s);
+        RC_REQUIRE(ok, RCFM_ERR_RUNTIME, "two-transform tile kernel refused a pair it should accept");
     }
     {   // inverse FFT last pass -> split + stereo mix -> packed L/R FFT first pass, per member of the pair
         const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);

@@ -1,0 +1,375 @@
+// Tuner.run + FM.run for a pair of narrow channels in ONE workgroup, every transform in LDS (lds_chain.h).
+//
+// LDS: xs = B complex (the signal being transformed), ds = B floats (the first member's phases): 12 B bytes, so
+// B <= 13 653 fits the 160 KiB of a CU (cfg5: B = 12 500 -> 150 000 bytes, one workgroup per CU).  Per pair:
+//   member 0: gather B bins (window, Nyquist merge: tuner.py:159-161) -> xs, IFFT_B in place, angle / pi -> ds
+//   member 1: the same -> angle / pi -> upper half of xs
+//   u[t] = d0[t] + j d1[t], d = wrapped phase step (fm.py:60-65, d[0] = 0)            -> xs
+//   FFT_B(u); keep |k| <= A/2, Hamming weight, Nyquist merge (decimate.py:48)         -> xs[0 .. A)
+//   IFFT_A: real part = member 0's audio, imaginary part = member 1's                  -> memory
+// The transforms are in-place decimation-in-frequency with three stages of composite radices (dft_nat, fft_kernel.h);
+// the last stage of each leaves its outputs in registers, from where they go to their natural-order place together
+// with the point-wise work (arctangent; decimation), so no separate reordering pass exists.  Inverse transforms use
+// the swap identity ifft(x) = swap(fft(swap(x))).  Stage twiddles: one entry of the global table W_L^e per butterfly
+// (L2-resident: 100 KB for B = 12 500), powers by product tree (twiddle_powers).
+
+#include "lds_chain.h"
+
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "device_math.h"
+#include "fft_kernel.h"
+
+namespace rcfm {
+
+namespace {
+
+using fftk::cmul;
+using fftk::dft_pa;
+using fftk::dft_slot;
+using fftk::lds_barrier;
+using fftk::twiddle_powers;
+
+// -DRCFM_LDS_CHAIN_TRACE (timing experiments): workgroup 0 records s_memtime at every phase boundary and the launcher
+// prints the differences after a synchronisation.
+#ifdef RCFM_LDS_CHAIN_TRACE
+#define RCFM_TRACE_POINT(i) \
+    do { if (blockIdx.x == 0 && threadIdx.x == 0) p.trace[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RCFM_TRACE_POINT(i) do { } while (0)
+#endif
+
+struct ChainDev {
+    long long* trace;             // RCFM_LDS_CHAIN_TRACE builds only
+    LdsChainArgs a;
+    float two_pi_over_n, delta;   // window argument of source offset d: d * 2 pi / N + delta
+    float c0, c1, c2, c3;         // a0 + (1 - a0) cos(th) as a series in th^2 (|th| < 0.25: fused_passes.hip)
+    const float2* twB;            // W_B^e, e < B
+    const float2* twA;            // W_A^e, e < A
+};
+
+// One in-place DIF stage on a single signal in LDS: block length MT entering the stage, radix R.
+template <int L, int R, int MT, int T>
+__device__ __forceinline__ void chain_stage(float2* x, const float2* __restrict__ tw, int tid) {
+    constexpr int m = MT / R, step = L / MT, rows = L / R;
+#pragma unroll 1
+    for (int b = tid; b < rows; b += T) {          // one sweep where rows <= T (every stage but B's 625-row one at T = 512)
+        const int g = b / m, kp = b - g * m;
+        const int base = g * MT + kp;
+        float2 v[R];
+        const float2 w1 = tw[kp * step];          // W_MT^kp, issued ahead of the LDS reads
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = x[base + q * m];
+        dft_pa<R>(v);
+        float2 pw[R];
+        twiddle_powers<R>(w1, pw);
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], pw[q]);
+#pragma unroll
+        for (int q = 0; q < R; ++q) x[base + q * m] = v[dft_slot<R>(q)];
+    }
+}
+
+// Last stage (block length R, no twiddle): butterfly g reads x[g R + q]; output q' is bin kb + (L / R) q' with
+// kb = q1 + R0 q2 for g = q1 R1 + q2.  Results stay in v (slot dft_slot<R>(q')).
+template <int L, int R0, int R1, int R, int T>
+__device__ __forceinline__ int chain_last(const float2* x, int tid, float2* v) {
+    static_assert(R0 * R1 * R == L, "three stages");
+    constexpr int rows = L / R;
+    static_assert(rows <= T, "one sweep per stage");
+    const int g = tid < rows ? tid : 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = x[g * R + q];
+    dft_pa<R>(v);
+    const int q1 = g / R1, q2 = g - q1 * R1;
+    return q1 + R0 * q2;
+}
+
+template <int B, int R0, int R1, int R2, int A, int Q0, int Q1, int Q2, int T>
+__global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
+    static_assert(R0 * R1 * R2 == B && Q0 * Q1 * Q2 == A, "radix lists");
+    static_assert(A % 2 == 0 && A < B && (size_t)B * 12 <= 160 * 1024, "geometry");
+    __shared__ __attribute__((aligned(16))) float2 xs[B];
+    __shared__ __attribute__((aligned(16))) float ds[B];
+    float* const th1 = reinterpret_cast<float*>(xs) + B;      // member 1's phases: upper half of xs
+    const int tid = threadIdx.x;
+    const int c0 = 2 * (int)blockIdx.x;
+    const bool has1 = c0 + 1 < p.a.count;
+    const int c1 = has1 ? c0 + 1 : c0;
+    constexpr int NL = (B + T - 1) / T;
+
+    auto window = [&](int d) -> float {
+        const float th = fmaf((float)d, p.two_pi_over_n, p.delta);
+        const float t = th * th;
+        return fmaf(t, fmaf(t, fmaf(t, p.c3, p.c2), p.c1), p.c0);
+    };
+
+    // ---- the two channels: gather -> IFFT_B -> phases --------------------------------------------------------
+#pragma unroll 1
+    for (int mem = 0; mem < 2; ++mem) {
+        RCFM_TRACE_POINT(mem * 6 + 0);
+        const float2* Xc = p.a.X + p.a.base[mem ? c1 : c0];
+        float2 v[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            int k = tid + T * it;
+            k = k < B ? k : B - 1;                              // ragged last sweep: clamped, not stored
+            v[it] = Xc[k < p.a.nyq ? k : k - B];
+        }
+        float2 m2 = make_float2(0.f, 0.f);                      // Y[+B/2] += X[-B/2] w(-B/2) (NYQ_DOWN)
+        if (p.a.merge >= 0) {
+            const float2 x2 = Xc[-p.a.merge];
+            const float w2 = window(-p.a.merge);
+            m2 = make_float2(x2.x * w2, x2.y * w2);
+        }
+        if (mem) lds_barrier();                                 // member 0's last stage has read all of xs
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int k = tid + T * it;
+            if (k < B) {
+                const float w = window(k < p.a.nyq ? k : k - B);
+                const float sel = (k == p.a.merge) ? 1.f : 0.f;
+                xs[k] = make_float2(fmaf(sel, m2.y, v[it].y * w), fmaf(sel, m2.x, v[it].x * w));   // swapped
+            }
+        }
+        lds_barrier();
+        RCFM_TRACE_POINT(mem * 6 + 1);
+        chain_stage<B, R0, B, T>(xs, p.twB, tid);
+        lds_barrier();
+        RCFM_TRACE_POINT(mem * 6 + 2);
+        chain_stage<B, R1, B / R0, T>(xs, p.twB, tid);
+        lds_barrier();
+        RCFM_TRACE_POINT(mem * 6 + 3);
+        float2 y[R2];
+        const int kb = chain_last<B, R0, R1, R2, T>(xs, tid, y);
+        if (mem) lds_barrier();                                 // th1 overlays xs: every read of xs is done
+        RCFM_TRACE_POINT(mem * 6 + 4);
+        if (tid < B / R2) {
+            float* dst = mem ? th1 : ds;
+#pragma unroll
+            for (int q = 0; q < R2; ++q) {
+                const float2 z = y[dft_slot<R2>(q)];           // swapped: re = z.y, im = z.x
+                dst[kb + (B / R2) * q] = atan2_over_pi(z.x, z.y);
+            }
+        }
+        RCFM_TRACE_POINT(mem * 6 + 5);
+    }
+    lds_barrier();
+    RCFM_TRACE_POINT(12);
+
+    // ---- u[t] = d0[t] + j d1[t]: the wrapped phase steps of both channels (fm.py:60-65) ---------------------------
+    {
+        float2 u[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            int t = tid + T * it;
+            t = t < B ? t : B - 1;
+            const int tp = t > 0 ? t - 1 : 0;
+            const float d0 = phase_step_wrapped(ds[t], ds[tp]);
+            const float d1 = phase_step_wrapped(th1[t], th1[tp]);
+            u[it] = t > 0 ? make_float2(d0, d1) : make_float2(0.f, 0.f);
+        }
+        lds_barrier();                                          // th1 is overwritten below, ds is free from here
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int t = tid + T * it;
+            if (t < B) xs[t] = u[it];
+        }
+    }
+    // The decimation's weights (A/2 + 1 folded Hamming values times 1/B) go to ds now: their global loads fly under
+    // FFT_B's first two stages instead of standing between its last stage and the stores.
+    {
+        constexpr int NW = (A / 2 + 1 + T - 1) / T;
+        float wv[NW];
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int k = tid + T * it;
+            wv[it] = p.a.wr[k <= A / 2 ? k : A / 2] * p.a.scale;
+        }
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int k = tid + T * it;
+            if (k <= A / 2) ds[k] = wv[it];
+        }
+    }
+    lds_barrier();
+    RCFM_TRACE_POINT(13);
+
+    // ---- FFT_B(u), decimation to A (decimate.py:48 for the packed pair: the weight is real and even) ---------------
+    chain_stage<B, R0, B, T>(xs, p.twB, tid);
+    lds_barrier();
+    RCFM_TRACE_POINT(14);
+    chain_stage<B, R1, B / R0, T>(xs, p.twB, tid);
+    lds_barrier();
+    RCFM_TRACE_POINT(15);
+    {
+        float2 y[R2];
+        const int kb = chain_last<B, R0, R1, R2, T>(xs, tid, y);
+        // rows of the short spectrum: kappa = k (k < A/2), k - (B - A) (k > B - A/2), the two Nyquist bins meet in A/2
+        // (k = B - A/2 is parked in slot A and added by one thread)
+        lds_barrier();                                          // every read of xs is done
+        if (tid < B / R2) {
+#pragma unroll
+            for (int q = 0; q < R2; ++q) {
+                const int k = kb + (B / R2) * q;
+                // kb < B / R2: the bins of this q lie in [(B/R2) q, (B/R2)(q + 1)); a range that misses both kept bands
+                // is decided at compile time, and the butterfly outputs nobody uses are not computed at all
+                if ((B / R2) * q > A / 2 && (B / R2) * (q + 1) <= B - A / 2) continue;
+                int kap = -1;
+                if (k <= A / 2) kap = k;
+                else if (k > B - A / 2) kap = k - (B - A);
+                else if (k == B - A / 2) kap = A;
+                if (kap >= 0) {
+                    const float w = ds[k <= A / 2 ? k : B - k];
+                    const float2 z = y[dft_slot<R2>(q)];
+                    const float2 val = make_float2(z.x * w, z.y * w);
+                    xs[kap] = make_float2(val.y, val.x);        // swapped: inverse transform
+                    if (k == 0 && p.a.dc != nullptr) {          // mean of each member's audio (the DC bin)
+                        p.a.dc[c0] = make_float2(val.x, 0.f);
+                        if (has1) p.a.dc[c1] = make_float2(val.y, 0.f);
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+    RCFM_TRACE_POINT(16);
+    if (tid == 0) {
+        const float2 a = xs[A / 2], b = xs[A];
+        xs[A / 2] = make_float2(a.x + b.x, a.y + b.y);
+    }
+    lds_barrier();
+
+    // ---- IFFT_A: real part -> member 0, imaginary part -> member 1 -----------------------------------------------
+    RCFM_TRACE_POINT(17);
+    chain_stage<A, Q0, A, T>(xs, p.twA, tid);
+    lds_barrier();
+    RCFM_TRACE_POINT(18);
+    chain_stage<A, Q1, A / Q0, T>(xs, p.twA, tid);
+    lds_barrier();
+    RCFM_TRACE_POINT(19);
+    {
+        float2 y[Q2];
+        const int kb = chain_last<A, Q0, Q1, Q2, T>(xs, tid, y);
+        lds_barrier();
+        if (tid < A / Q2) {
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) xs[kb + (A / Q2) * q] = y[dft_slot<Q2>(q)];    // natural order, swapped
+        }
+    }
+    lds_barrier();
+    RCFM_TRACE_POINT(20);
+    float* out0 = p.a.audio + (int64_t)c0 * A;
+    float* out1 = p.a.audio + (int64_t)c1 * A;
+    if constexpr (A % 4 == 0) {
+        for (int i = tid; i < A / 4; i += T) {
+            const float2 s0 = xs[4 * i], s1 = xs[4 * i + 1], s2 = xs[4 * i + 2], s3 = xs[4 * i + 3];
+            reinterpret_cast<float4*>(out0)[i] = make_float4(s0.y, s1.y, s2.y, s3.y);
+            if (has1) reinterpret_cast<float4*>(out1)[i] = make_float4(s0.x, s1.x, s2.x, s3.x);
+        }
+    } else {
+        for (int i = tid; i < A; i += T) {
+            const float2 s0 = xs[i];
+            out0[i] = s0.y;
+            if (has1) out1[i] = s0.x;
+        }
+    }
+    RCFM_TRACE_POINT(21);
+}
+
+// (B; R0, R1, R2 | A; Q0, Q1, Q2 | threads): each stage has at most `threads` butterflies.
+#ifndef RCFM_LDS_CHAIN_T
+#define RCFM_LDS_CHAIN_T 512   // 640 threads (one sweep in every stage) spill 87 dwords at 168 VGPRs: 1.13 vs 0.81 ms on cfg5
+#endif
+#define RCFM_LDS_CHAINS(X)                          \
+    X(12500, 25, 20, 25, 8000, 20, 20, 20, RCFM_LDS_CHAIN_T)     \
+    X(12500, 25, 20, 25, 6250, 25, 10, 25, 640)     \
+    X(10000, 20, 20, 25, 8000, 20, 20, 20, 512)     \
+    X(12000, 24, 20, 25, 8000, 20, 20, 20, 640)
+
+const float2* twiddle_table(int n) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::unique_ptr<DeviceBuffer>> tables;   // (device, n)
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = tables.find({dev, n});
+    if (it == tables.end()) {
+        std::vector<float2> tw((size_t)n);
+        for (int e = 0; e < n; ++e) {
+            const double a = -6.28318530717958647692 * (double)e / (double)n;
+            tw[(size_t)e] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        auto buf = std::make_unique<DeviceBuffer>();
+        buf->upload(tw.data(), tw.size() * sizeof(float2));
+        it = tables.emplace(std::make_pair(dev, n), std::move(buf)).first;
+    }
+    return it->second->as<float2>();
+}
+
+void trace_report(const ChainDev& p, hipStream_t stream) {
+#ifdef RCFM_LDS_CHAIN_TRACE
+    static const char* const names[21] = {
+        "m0 gather", "m0 stage 1", "m0 stage 2", "m0 last", "m0 atan2", "(loop)", "m1 gather", "m1 stage 1", "m1 stage 2",
+        "m1 last", "m1 atan2", "(barrier)", "phase steps", "F stage 1", "F stage 2", "F last+decim", "nyquist",
+        "A stage 1", "A stage 2", "A last+reorder", "store"};
+    long long t[22];
+    RC_HIP(hipStreamSynchronize(stream));
+    RC_HIP(hipMemcpy(t, p.trace, sizeof(t), hipMemcpyDeviceToHost));
+    fprintf(stderr, "lds_chain trace (s_memtime ticks, workgroup 0): total %lld\n", t[21] - t[0]);
+    for (int i = 0; i < 21; ++i) fprintf(stderr, "  %-16s %7lld\n", names[i], t[i + 1] - t[i]);
+#else
+    (void)p;
+    (void)stream;
+#endif
+}
+
+}  // namespace
+
+bool lds_chain_supported(int B, int A) {
+#define RCFM_CASE(B_, R0, R1, R2, A_, Q0, Q1, Q2, T_) \
+    if (B == B_ && A == A_) return true;
+    RCFM_LDS_CHAINS(RCFM_CASE)
+#undef RCFM_CASE
+    return false;
+}
+
+bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream) {
+    if (args.count <= 0) return true;
+    if (!lds_chain_supported(B, A)) return false;
+    ChainDev p;
+    p.trace = nullptr;
+#ifdef RCFM_LDS_CHAIN_TRACE
+    static DeviceBuffer trace_buf(32 * sizeof(long long));
+    p.trace = trace_buf.as<long long>();
+#endif
+    p.a = args;
+    const double a0 = 0.5, a1 = 1.0 - a0;                      // fftshifted periodic Hann (tuner.py:156-157)
+    p.two_pi_over_n = (float)(6.28318530717958647692 / (double)args.N);
+    p.delta = (args.N % 2) ? (float)(3.14159265358979323846 / (double)args.N) : 0.f;
+    p.c0 = (float)(a0 + a1);
+    p.c1 = (float)(-a1 / 2.0);
+    p.c2 = (float)(a1 / 24.0);
+    p.c3 = (float)(-a1 / 720.0);
+    p.twB = twiddle_table(B);
+    p.twA = twiddle_table(A);
+    const dim3 grid((unsigned)((args.count + 1) / 2));
+#define RCFM_CASE(B_, R0, R1, R2, A_, Q0, Q1, Q2, T_)                                                        \
+    if (B == B_ && A == A_) {                                                                                \
+        hipLaunchKernelGGL((k_fm_lds<B_, R0, R1, R2, A_, Q0, Q1, Q2, T_>), grid, dim3(T_), 0, stream, p);   \
+        RC_HIP(hipGetLastError());                                                                           \
+        trace_report(p, stream);                                                                             \
+        return true;                                                                                         \
+    }
+    RCFM_LDS_CHAINS(RCFM_CASE)
+#undef RCFM_CASE
+    return false;
+}
+
+}  // namespace rcfm

@@ -48,7 +48,7 @@ class Demodulator(Injector):
             hip.check(self._lib.rcfm_demod_create(self._KIND, self._batch, self._input_size, self._output_size,
                                                   self._tau, self._chunk, ctypes.byref(h)))
             self._h = hip.Handle(h, self._lib.rcfm_demod_destroy)
-            self._apply_binding()
+            self._apply_binding(move_history=0)      # new handle: the batched caller has carried the state so far
         return self._h
 
     def _bind(self, batched_handle, index):
@@ -56,16 +56,17 @@ class Demodulator(Injector):
         (rcfm_demod_bind_state: one state per channel, whoever runs it -- deemphasis.py:48-49,64)."""
         self._binding = (weakref.ref(batched_handle), int(index))
         if self._h is not None:
-            self._apply_binding()
+            self._apply_binding(move_history=1)      # this object has run before: its history goes with it
 
-    def _apply_binding(self):
+    def _apply_binding(self, move_history):
         if self._binding is None:
             return
         owner = self._binding[0]()
         if owner is None or not owner.value:      # the tuner is gone: the state is this object's own again
             self._binding = None
             return
-        hip.check(self._lib.rcfm_demod_bind_state(self._h.value, owner.value, self._binding[1], hip.stream()))
+        hip.check(self._lib.rcfm_demod_bind_state(self._h.value, owner.value, self._binding[1], int(move_history),
+                                                  hip.stream()))
 
     @property
     def channels(self):

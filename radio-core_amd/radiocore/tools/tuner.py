@@ -308,7 +308,7 @@ class Tuner(Injector):
         if owner is None:
             self._state_owner[owner_key] = handle
         elif owner.value != handle.value:
-            hip.check(self._lib.rcfm_demod_bind_state(handle.value, owner.value, 0, hip.stream()))
+            hip.check(self._lib.rcfm_demod_bind_state(handle.value, owner.value, 0, 0, hip.stream()))   # the owner has the history
         geo = (kind, B, A, tau)
         seen = set()
         for c in self._bounds:

@@ -89,23 +89,49 @@ def test_run_all_a_not_multiple_of_four(rc, oracle, kind, A):
             assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index)
 
 
-def test_run_all_narrowband_fm_geometry(rc, oracle):
-    """cfg5's channel geometry (12.5 kHz FM channels -> 8 kHz audio: B = 12 500 = 100 x 125, the 125 -> 80
-    decimating tile) at a reduced band: N = 1e6, 81 channels on the 12 kHz raster, default chunk."""
-    N, B, A, C = 1_000_000, 12500, 8000, 81
+@pytest.mark.parametrize("kind,A,chunk", [("FM", 8000, 0), ("MFM", 8000, 0), ("FM", 8000, 7), ("MFM", 6250, 0),
+                                          ("FM", 5000, 0)])
+def test_run_all_narrowband_fm_geometry(rc, oracle, kind, A, chunk):
+    """cfg5's channel geometry (12.5 kHz channels, 12 kHz raster) at a reduced band: N = 1e6, 81 channels.
+    B = 12 500 -> A = 8000 / 6250 run the whole chain of a channel pair in one workgroup, every transform in LDS
+    (lds_chain.hip): odd channel count and chunks of 7 leave lone pair members; MFM adds the de-emphasis kernel and
+    its carried state (two buffers).  A = 5000 has no LDS instantiation and stays on the multi-pass launches
+    (B = 100 x 125, the 125 -> 40 ... decimation falls back to the generic path): both must agree with the reference
+    loop (tuner.py:151-161, fm.py:60-67, mfm.py:62-66)."""
+    N, B, C = 1_000_000, 12500, 81
+    centres = workloads.channel_grid(C, 12000)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.1, stereo=False, deviation=2500.0)
+    for buf in range(2 if kind == "MFM" else 1):
+        xb = np.roll(x, 4242 * buf)
+        tuner.load(xb)
+        ref.load(xb)
+        audio = tuner.run_all(chunk=chunk)
+        assert audio.shape == (C, A, 1)
+        for c in ref.channels():
+            iq = ref.run_pruned(c.index)
+            if c.index in (0, 40, 80) and buf == 0:
+                assert rel_err(tuner.run(c.index), iq) <= TOL, c.index
+            want = np.asarray(c.demodulator.run(iq)).reshape(A, 1)
+            assert rel_err(audio[c.index], want) <= TOL, (kind, A, buf, c.index, rel_err(audio[c.index], want))
+
+
+def test_lds_chain_pairing_does_not_matter(rc, oracle):
+    """The same narrow band through the LDS-resident kernel and (RCFM_LDS_CHAIN=0 is read once per process, so
+    through a sharded call that starts at an odd channel index instead) a different pairing: a channel's audio must
+    not depend on which neighbour shares its complex transform beyond float32 rounding."""
+    N, B, A, C = 1_000_000, 12500, 8000, 20
     centres = workloads.channel_grid(C, 12000)
     tuner, ref = _pair(rc, oracle, "FM", centres, B, A, N)
     x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.1, stereo=False, deviation=2500.0)
     tuner.load(x)
-    ref.load(x)
-    audio = tuner.run_all()
-    assert audio.shape == (C, A, 1)
-    for c in ref.channels():
-        iq = ref.run_pruned(c.index)
-        if c.index in (0, 40, 80):
-            assert rel_err(tuner.run(c.index), iq) <= TOL, c.index
-        want = np.asarray(c.demodulator.run(iq)).reshape(A, 1)
-        assert rel_err(audio[c.index], want) <= TOL, c.index
+    full = tuner.run_all()
+    tuner.shard(3, 11)                   # channels 3..13: pairs (3,4) (5,6) ... instead of (2,3) (4,5) ...
+    tuner.load(x)
+    part = tuner.run_all()
+    assert part.shape == (11, A, 1)
+    for i in range(11):
+        assert rel_err(part[i], full[3 + i]) <= 0.05 * TOL, i
 
 
 @pytest.mark.parametrize("kind,B", [("FM", 375000), ("MFM", 337500)])

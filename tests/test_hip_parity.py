@@ -399,7 +399,7 @@ def test_feeder_keeps_temporaries_alive_until_their_copy_has_landed(rc):
     N, B, A, K = 600000, 60000, 12000, 6
     centres = [100e6, 100.1e6]
     base = workloads.wideband(N, 100e6, centres, B, gain=0.5)
-    t = rc.Tuner()
+    t = rc.Tuner(cuda=True)
     for f in centres:
         t.add_channel(f, B, rc.FM(B, A))
     t.request_bandwidth(float(N))
