@@ -383,15 +383,22 @@ def main():
                     help="worker processes of the parallel ('fair') CPU baseline; 0 = size the pool from the host: "
                          "min(logical cores // 2, MemAvailable // 10 GB) -- each worker holds ~8 GB while it rolls "
                          "and windows the 240M-point spectrum; 1 = skip")
+    ap.add_argument("--parallelism", default="replicated", choices=["replicated", "rotating"],
+                    help="N > 1: 'replicated' = every rank runs the whole wideband FFT and its own channels; 'rotating' = "
+                         "rank i mod N owns buffer i (ingest + FFT) and sends each peer the spectrum bins its channels "
+                         "read over xGMI (radiocore.tools.sharding.SpectrumRing); both gather the audio with RCCL")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other GPU configurations (cfg3, cfg5, batched cfg2) reported beside the headline")
     ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-fed path: page-locked host buffer, H2D of buffer i+1 on a copy "
-                         "stream overlapped with the kernels of buffer i (extra field pcie_inclusive; never `value`)")
+                         "stream overlapped with the kernels of buffer i (extra field pcie_inclusive; never `value`); "
+                         "always on for N > 1")
     args = ap.parse_args()
 
     rank, world, local = dist_env()
+    if world > 1:
+        args.pcie = True           # the N > 1 line always carries pcie_inclusive (0.1 - 0.7 s of extra run time)
     # Dry run of the N > 1 code on a one-GPU box (tests/test_bench_multirank.py): RCFM_BENCH_DEVICE puts every rank on
     # that device and RCFM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); the audio blocks then
     # travel through host memory.  The numbers of such a run mean nothing.
@@ -432,6 +439,19 @@ def main():
     demod = ctypes.c_void_p()
     kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
     hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
+    rotating = args.parallelism == "rotating"
+    ring = surf = None
+    if rotating:
+        # the rotating owner runs through the class surface (Tuner + one demodulator object per channel): the ring
+        # swaps the tuner's spectrum storage between buffers, which the surface exposes (attach / window / adopt)
+        import radiocore as rc
+        surf = rc.Tuner(cuda=True)
+        for f in centres:
+            surf.add_channel(f, B, getattr(rc, kind)(B, A, cuda=True))
+        surf.request_bandwidth(float(N))
+        ring = sharding.SpectrumRing(surf, N, C)
+        for j in range(ring.lookahead):                       # prime: `lookahead` buffers in flight from here on
+            ring.submit(j, x if ring.owner(j) == rank else None)
     # N > 1: the audio blocks are double-buffered so that the gather of buffer i (RCCL's own stream, xGMI)
     # overlaps the kernels of buffer i+1; every gather completes inside the timed region (barrier()).
     nbuf = 2 if multi else 1
@@ -441,6 +461,7 @@ def main():
                  for _ in range(nbuf)]
     in_flight = [None] * nbuf
     counter = [0]
+    source = [x]               # what an owner ingests: the resident buffer, or (pcie_inclusive) page-locked host memory
 
     def step():
         s = hip.stream()
@@ -449,9 +470,16 @@ def main():
         if in_flight[slot] is not None:
             in_flight[slot].wait()          # stream-ordered: this slot's previous block has left
             in_flight[slot] = None
-        hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
-        # pipeline_run addresses channels of tuner and demod by the same index
-        hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audios[slot]), s))
+        if rotating:
+            i = counter[0] - 1
+            j = i + ring.lookahead
+            ring.submit(j, source[0] if ring.owner(j) == rank else None)   # owner of buffer j: ingest + FFT + sends
+            ring.acquire(i)                                                # buffer i's bins for this rank's channels
+            audios[slot] = surf.run_all(numpy_output=False)
+        else:
+            hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
+            # pipeline_run addresses channels of tuner and demod by the same index
+            hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audios[slot]), s))
         if multi and backend == "nccl":     # RCCL over xGMI: the only collective on the path
             in_flight[slot] = sharding.gather_audio(audios[slot], C, dst=0, out=gathereds[slot], async_op=True)
         elif multi:                         # dry run: same protocol through host memory
@@ -476,9 +504,11 @@ def main():
     # pass 1 (untimed): every stage bracketed, to find the dominant one
     lib.rcfm_profile_reset()
     lib.rcfm_profile_enable(ctypes.c_uint64((1 << lib.rcfm_profile_stage_count()) - 1))
-    step()
+    prof_steps = world if rotating else 1      # a rank runs the wideband FFT once per `world` buffers when it rotates
+    for _ in range(prof_steps):
+        step()
     torch.cuda.synchronize()
-    prof_all = read_profile(lib)
+    prof_all = {k: (st, ms / prof_steps, cnt) for k, (st, ms, cnt) in read_profile(lib).items()}
     lib.rcfm_profile_enable(ctypes.c_uint64(0))
     dominant = max(prof_all, key=lambda k: prof_all[k][1])
     if args.profile_all and rank == 0:
@@ -542,8 +572,11 @@ def main():
             "workload": "%s: %d-channel Tuner at %d MSPS complex64 -> %d x %s (%d -> %d Hz), 1-second buffers, "
                         "input resident in HBM" % (args.config, C, N // 1_000_000, C, kind, B, A),
             "channels": C, "channels_per_gpu": mine, "wideband_samples": N, "channel_samples": B,
-            "audio_samples": A, "parallelism": "channels sharded x%d, wideband FFT replicated, RCCL gather" % world
-            if world > 1 else "single GPU",
+            "audio_samples": A, "parallelism": (
+                "channels sharded x%d, rotating FFT owner (rank i mod %d ingests and transforms buffer i, peers receive "
+                "their spectrum windows over xGMI, %d buffers in flight), RCCL gather" % (world, world, ring.lookahead)
+                if rotating else "channels sharded x%d, wideband FFT replicated, RCCL gather" % world
+                if world > 1 else "single GPU"),
         },
         "path_hbm_frac": round(total_alg / (ms_per_step * 1e-3) / HBM_PEAK, 4),
         "path_hbm_frac_read": round(total_read / (ms_per_step * 1e-3) / HBM_PEAK, 4),
@@ -568,9 +601,18 @@ def main():
         chan_ms = max(ms_per_step - fft_ms, 1e-6)
         result["channel_stage_value"] = {
             "value": round(C * B / (chan_ms * 1e-3) / 1e6, 1), "unit": "channel Msamples/s",
-            "note": "all %d channels' samples / (step time - the replicated wideband FFT, %.3f ms on rank 0)" % (C, fft_ms)}
+            "note": "all %d channels' samples / (step time - this rank's wideband-FFT time per buffer, %.3f ms on rank 0%s)"
+                    % (C, fft_ms, ": one transform every %d buffers" % world if rotating else ", replicated")}
         alg_fft, alg_all = 16.0 * N, path_bytes(N, C, B, A, kind)
-        result["amdahl_bound_speedup"] = round(alg_all / (alg_fft + (alg_all - alg_fft) / world), 3)
+        # replicated FFT: Amdahl; rotating owner: every stage divides by the world size
+        result["amdahl_bound_speedup"] = float(world) if rotating else round(
+            alg_all / (alg_fft + (alg_all - alg_fft) / world), 3)
+        if rotating:
+            result["rotating_owner"] = {
+                "lookahead": ring.lookahead, "spectrum_slots": len(ring.slots),
+                "window_bins_of_rank0": int(sum(b - a for a, b in ring.segments[0])),
+                "bytes_sent_per_owned_buffer": int(ring.bytes_sent_per_buffer()),
+                "ffts_per_rank_per_buffer": round(1.0 / world, 4)}
 
         # the last gathered block (outside the timed region): every rank's rows arrived
         step()
@@ -585,46 +627,67 @@ def main():
                 "own_block_equal": bool(torch.equal(g[lo:hi], audios[(counter[0] - 1) % nbuf])),
             }
 
-    if args.pcie and world == 1:
-        # Host-fed variant through the package's ingest component: the wideband buffer
-        # starts in page-locked host memory (radiocore.tools.Buffer(cuda=True)); radiocore.tools.Feeder keeps two
-        # device slots and copies buffer i+1 on its own stream while buffer i is processed.  Steady state is
-        # bound by max(copy, compute).
+    if args.pcie:
+        # Host-fed variant (DESIGN.md sections 4, 5): the wideband buffer starts in page-locked host memory
+        # (radiocore.tools.Buffer(cuda=True)) and crosses PCIe inside the loop.
+        #   replicated: EVERY rank copies the whole buffer over its own link (radiocore.tools.Feeder: two device
+        #               slots, buffer i+1 copied on its own stream under the kernels of buffer i);
+        #   rotating:   only the owner of a buffer copies it (SpectrumRing stages it on its FFT stream), so each link
+        #               carries 1/N of the buffers.
         from radiocore.tools import Buffer, Feeder
         host = Buffer(N, dtype=np.complex64, cuda=True)
         host.data[:] = x.cpu().numpy()
-        feeder = Feeder(N, dtype=np.complex64, depth=2)
-
-        def consume():
-            with feeder.next() as xd:
-                hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(xd), hip.stream()))
-                hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), hip.stream()))
-
-        feeder.submit(host.data)
-        consume()
-        torch.cuda.synchronize()
         k = max(args.steps, 4)
-        t0 = time.perf_counter()
-        feeder.submit(host.data)
-        for i in range(k):
-            if i + 1 < k:
-                feeder.submit(host.data)
-            consume()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / k
-        result["pcie_inclusive"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(N / dt / 1e6, 1),
-                                    "unit": "Msamples/s", "h2d_GBps": None,
-                                    "note": "radiocore.tools.Feeder: page-locked host buffer, H2D of buffer i+1 "
-                                            "overlapped with the kernels of buffer i"}
-        t0 = time.perf_counter()
-        feeder.submit(host.data)
-        with feeder.next():
-            pass
-        torch.cuda.synchronize()
-        result["pcie_inclusive"]["h2d_GBps"] = round(N * 8 / (time.perf_counter() - t0) / 1e9, 1)
-        del feeder, host
+        if rotating:
+            source[0] = host._owner.view(torch.complex64)      # the same pinned pages as a torch tensor
+            for _ in range(ring.lookahead + 1):                 # the buffers already in flight came from HBM
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            barrier()
+            dt = (time.perf_counter() - t0) / k
+            source[0] = x
+            note = "rotating owner: buffer i crosses PCIe on rank i mod %d only, on that rank's FFT stream" % world
+        else:
+            feeder = Feeder(N, dtype=np.complex64, depth=2)
 
-    if rank == 0 and world == 1 and args.cpu_channels > 0:
+            def consume():
+                with feeder.next() as xd:
+                    hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(xd), hip.stream()))
+                    hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audio), hip.stream()))
+
+            feeder.submit(host.data)
+            consume()
+            barrier()
+            t0 = time.perf_counter()
+            feeder.submit(host.data)
+            for i in range(k):
+                if i + 1 < k:
+                    feeder.submit(host.data)
+                consume()
+            barrier()
+            dt = (time.perf_counter() - t0) / k
+            note = ("radiocore.tools.Feeder: page-locked host buffer, H2D of buffer i+1 overlapped with the kernels of "
+                    "buffer i" + ("; every rank copies the whole buffer over its own link" if world > 1 else ""))
+        if multi:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        result["pcie_inclusive"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(N / dt / 1e6, 1),
+                                    "unit": "Msamples/s", "h2d_GBps": None, "note": note}
+        if not rotating:
+            t0 = time.perf_counter()
+            feeder.submit(host.data)
+            with feeder.next():
+                pass
+            torch.cuda.synchronize()
+            result["pcie_inclusive"]["h2d_GBps"] = round(N * 8 / (time.perf_counter() - t0) / 1e9, 1)
+            feeder.close()
+        del host
+
+    if rank == 0 and world == 1 and args.cpu_channels > 0 and not rotating and not multi:
         x_host = x.cpu().numpy()
         ref_audio, result["cpu_baseline"] = cpu_baseline(x_host, f_in, centres, N, C, B, A, kind,
                                                          args.cpu_channels, fair_workers(args.cpu_workers))
@@ -643,9 +706,12 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    if rotating:
+        ring.drain()               # the buffers still in flight: every posted transfer completes before the group goes
+        torch.cuda.synchronize()
     hip.check(lib.rcfm_demod_destroy(demod))
     hip.check(lib.rcfm_tuner_destroy(tuner))
-    if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras:
+    if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras and not multi:
         # the other GPU configurations of BASELINE.json on the same box, outside the headline's timed region
         surface4 = measure_surface("cfg4", x, centres, args.steps, args.warmup, ms_per_step * 1e-3)
         del x, audios, audio

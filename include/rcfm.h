@@ -95,6 +95,20 @@ int rcfm_tuner_shard(rcfm_tuner_t t, int first, int count);
 int rcfm_tuner_run(rcfm_tuner_t t, int first, int count, void* out, void* stream);
 /* Device pointer of the stored spectrum X [n] complex64 (Tuner._buffer). */
 int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X);
+/* ---- the spectrum as an object that can travel (multi-GPU: rotating FFT owner, radiocore/tools/sharding.py) ------
+ * Tuner.load (tuner.py:126-138) keeps the spectrum in `self._buffer`; with channels sharded over G GPUs only ONE GPU
+ * needs to run the wideband FFT of a given buffer, if it then hands every peer the bins that peer's channels read.
+ *   spectrum_layout   storage = [halo | n bins | halo] complex64 (the halos repeat the far ends)
+ *   attach_spectrum   use caller-owned storage of that layout instead of the handle's own (NULL: back to its own);
+ *                     loaded_count > 0 declares that it already holds the bins of channels [loaded_first, +count)
+ *   window            the bins channels [first, first + count) read: [first_bin, first_bin + nbins) modulo n, whole
+ *                     rows of the forward plan (nbins = n: no window, everything)
+ *   adopt             the caller has written those bins into the storage (received them over xGMI): refresh the
+ *                     halos and accept exactly that channel range in rcfm_tuner_run / rcfm_pipeline_run          */
+int rcfm_tuner_spectrum_layout(rcfm_tuner_t t, int64_t* halo, int64_t* n);
+int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, int loaded_count);
+int rcfm_tuner_window(rcfm_tuner_t t, int first, int count, int64_t* first_bin, int64_t* nbins);
+int rcfm_tuner_adopt(rcfm_tuner_t t, int first, int count, void* stream);
 int rcfm_tuner_destroy(rcfm_tuner_t t);
 
 /* ---- demodulators (radiocore/analog/{fm,mfm,wbfm}.py) --------------------- */

@@ -270,7 +270,8 @@ struct rcfm_tuner_s {
     DeviceBuffer base_dev;   // int32 (n - roll) mod n per channel: start of the channel in the haloed spectrum
     DeviceBuffer X;          // [halo | n bins | halo]: the halos repeat the far ends, so a channel's bins
     int64_t halo = 0;        //   base + d, |d| <= B/2 + 1, need no wrap-around (fused_passes.h)
-    float2* spectrum() { return X.as<float2>() + halo; }
+    float2* ext = nullptr;   // rcfm_tuner_attach_spectrum: caller-owned storage of the same layout instead of X
+    float2* spectrum() { return (ext ? ext : X.as<float2>()) + halo; }
     DeviceBuffer work;
     std::unique_ptr<FftPlan> forward;          // rocFFT fallback for lengths outside the engine
     std::unique_ptr<FftEngine> forward_engine;
@@ -286,15 +287,14 @@ struct rcfm_tuner_s {
     bool loaded_windowed = false;
     int loaded_first = 0, loaded_count = 0;
 
-    void shard(int first, int count) {
-        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
-        windowed = false;
-        shard_first = first;
-        shard_count = count;
-        if (!forward_engine || count == 0) return;
+    // Rows of the spectrum (row = n_1 consecutive bins, n_1 = the forward plan's first pass length) that channels
+    // [first, first + count) read, as a circular window lo..hi: everything but the longest run of unused rows.
+    // false: no engine, too few rows, or nothing worth skipping -- the range reads (nearly) the whole spectrum.
+    bool row_window(int first, int count, FftRowWindow* w) const {
+        if (!forward_engine || count == 0) return false;
         const int64_t f0 = forward_engine->row_length();
         const int64_t rows = n / f0;
-        if (rows < 64) return;
+        if (rows < 64) return false;
         std::vector<char> used((size_t)rows, 0);
         for (int c = first; c < first + count; ++c) {
             const int64_t centre = (n - roll[c]) % n, h = bw[c] / 2 + 2;
@@ -314,10 +314,56 @@ struct rcfm_tuner_s {
                 run = 0;
             }
         }
-        if (best_len < rows / 64 || best_len >= rows) return;   // nothing worth skipping (or nothing used)
-        window.lo = (int)((best_start + best_len) % rows);
-        window.hi = (int)(((best_start - 1) % rows + rows) % rows);
-        windowed = true;
+        if (best_len < rows / 64 || best_len >= rows) return false;   // nothing worth skipping (or nothing used)
+        w->lo = (int)((best_start + best_len) % rows);
+        w->hi = (int)(((best_start - 1) % rows + rows) % rows);
+        return true;
+    }
+
+    void shard(int first, int count) {
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
+        shard_first = first;
+        shard_count = count;
+        windowed = row_window(first, count, &window);
+    }
+
+    // The same window in bins: [first_bin, first_bin + nbins) modulo n (nbins = n: everything).
+    void bin_window(int first, int count, int64_t* first_bin, int64_t* nbins) const {
+        FftRowWindow w{0, 0};
+        if (!row_window(first, count, &w)) {
+            *first_bin = 0;
+            *nbins = n;
+            return;
+        }
+        const int64_t f0 = forward_engine->row_length(), rows = n / f0;
+        *first_bin = (int64_t)w.lo * f0;
+        *nbins = (((int64_t)w.hi - w.lo + rows) % rows + 1) * f0;
+    }
+
+    // The caller has written the bins channels [first, first + count) read (bin_window) into the spectrum storage,
+    // e.g. received them from the GPU that ran the wideband FFT of this buffer: repeat the ends in the halos
+    // (what the last FFT pass does for a local load) and accept exactly that channel range.
+    void adopt(int first, int count, hipStream_t s) {
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
+        int64_t fb = 0, nb = 0;
+        bin_window(first, count, &fb, &nb);
+        if (halo > 0) {
+            float2* Xs = spectrum();
+            // segments of the window: [fb, min(fb + nb, n)) and, when it wraps, [0, fb + nb - n)
+            const int64_t seg[2][2] = {{fb, std::min(fb + nb, n)}, {0, fb + nb > n ? fb + nb - n : 0}};
+            for (auto& g : seg) {
+                const int64_t a0 = std::max<int64_t>(g[0], 0), a1 = std::min<int64_t>(g[1], halo);   // bins [0, halo) -> behind the end
+                if (a1 > a0)
+                    RC_HIP(hipMemcpyAsync(Xs + n + a0, Xs + a0, sizeof(float2) * (size_t)(a1 - a0), hipMemcpyDeviceToDevice, s));
+                const int64_t b0 = std::max<int64_t>(g[0], n - halo), b1 = std::min<int64_t>(g[1], n);     // bins [n - halo, n) -> in front
+                if (b1 > b0)
+                    RC_HIP(hipMemcpyAsync(Xs + (b0 - n), Xs + b0, sizeof(float2) * (size_t)(b1 - b0), hipMemcpyDeviceToDevice, s));
+            }
+        }
+        loaded = true;
+        loaded_windowed = nb < n;
+        loaded_first = first;
+        loaded_count = count;
     }
     struct Band {
         ResampleGeom geom;
@@ -1010,6 +1056,45 @@ int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X) {
     return guarded([&] {
         RC_REQUIRE(t && X, RCFM_ERR_ARG, "NULL argument");
         *X = t->spectrum();
+    });
+}
+
+int rcfm_tuner_spectrum_layout(rcfm_tuner_t t, int64_t* halo, int64_t* n) {
+    return guarded([&] {
+        RC_REQUIRE(t && halo && n, RCFM_ERR_ARG, "NULL argument");
+        *halo = t->halo;
+        *n = t->n;
+    });
+}
+
+int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, int loaded_count) {
+    return guarded([&] {
+        RC_REQUIRE(t != nullptr, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(loaded_count <= 0 || (loaded_first >= 0 && loaded_first + loaded_count <= t->nch), RCFM_ERR_INDEX,
+                   "channel index out of range");
+        t->ext = static_cast<float2*>(storage);
+        // what the storage holds: the bins of channels [loaded_first, loaded_first + loaded_count), or nothing yet
+        t->loaded = loaded_count > 0;
+        int64_t fb = 0, nb = t->n;
+        if (t->loaded) t->bin_window(loaded_first, loaded_count, &fb, &nb);
+        t->loaded_windowed = t->loaded && nb < t->n;
+        t->loaded_first = loaded_first;
+        t->loaded_count = std::max(loaded_count, 0);
+    });
+}
+
+int rcfm_tuner_window(rcfm_tuner_t t, int first, int count, int64_t* first_bin, int64_t* nbins) {
+    return guarded([&] {
+        RC_REQUIRE(t && first_bin && nbins, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= t->nch, RCFM_ERR_INDEX, "channel index out of range");
+        t->bin_window(first, count, first_bin, nbins);
+    });
+}
+
+int rcfm_tuner_adopt(rcfm_tuner_t t, int first, int count, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(t != nullptr, RCFM_ERR_ARG, "NULL argument");
+        t->adopt(first, count, as_stream(stream));
     });
 }
 

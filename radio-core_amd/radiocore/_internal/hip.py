@@ -44,6 +44,10 @@ SIGNATURES = {
     "rcfm_tuner_shard": [_vp, _i, _i],
     "rcfm_tuner_run": [_vp, _i, _i, _vp, _vp],
     "rcfm_tuner_spectrum": [_vp, ctypes.POINTER(_vp)],
+    "rcfm_tuner_spectrum_layout": [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "rcfm_tuner_attach_spectrum": [_vp, _vp, _i, _i],
+    "rcfm_tuner_window": [_vp, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "rcfm_tuner_adopt": [_vp, _i, _i, _vp],
     "rcfm_tuner_destroy": [_vp],
     "rcfm_demod_create": [_i, _i, _i, _i, _dbl, _i, ctypes.POINTER(_vp)],
     "rcfm_demod_run": [_vp, _i, _i, _vp, _vp, _vp],

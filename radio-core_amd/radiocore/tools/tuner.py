@@ -156,13 +156,51 @@ class Tuner(Injector):
         if self._handle is not None:
             hip.check(self._lib.rcfm_tuner_shard(self._handle.value, int(first), int(count)))
 
-    def load(self, input_signal):
-        """Forward FFT of the one-second buffer; kept on the device (tuner.py:126-138)."""
+    def load(self, input_signal, whole=False):
+        """Forward FFT of the one-second buffer; kept on the device (tuner.py:126-138).
+
+        whole=True (multi-GPU, rotating FFT owner): keep every row any channel reads although this process is
+        sharded -- the spectrum is about to be handed to the other ranks (sharding.SpectrumRing)."""
         x = hip.to_device(input_signal, self._torch.complex64)
         n = int(x.shape[0])
-        hip.check(self._lib.rcfm_tuner_load(self._device_tuner(n), hip.ptr(x), hip.stream()))
+        h = self._device_tuner(n)
+        if whole and self._shard is not None:
+            hip.check(self._lib.rcfm_tuner_shard(h, 0, len(self._bounds)))
+        hip.check(self._lib.rcfm_tuner_load(h, hip.ptr(x), hip.stream()))
+        if whole and self._shard is not None:
+            hip.check(self._lib.rcfm_tuner_shard(h, self._shard[0], self._shard[1]))
         self._input = x            # keeps the buffer alive until the FFT has consumed it
         self._loaded_size = n
+
+    # ---- the spectrum as an object that can travel (rcfm_tuner_attach_spectrum / _window / _adopt) ---------------
+
+    def spectrum_slot(self, n):
+        """Device storage for one spectrum of an n-sample buffer: complex64 [halo + n + halo] (torch owns it)."""
+        halo, nn = ctypes.c_int64(), ctypes.c_int64()
+        hip.check(self._lib.rcfm_tuner_spectrum_layout(self._device_tuner(int(n)), ctypes.byref(halo), ctypes.byref(nn)))
+        t = hip.empty((int(nn.value) + 2 * int(halo.value),), self._torch.complex64)
+        t.rcfm_halo = int(halo.value)
+        return t
+
+    def attach(self, slot, n, loaded=None):
+        """Use `slot` (from spectrum_slot) as the spectrum from now on; loaded = (first, count): it already holds the
+        bins those channels read (None: nothing yet -- a load or adopt must follow)."""
+        first, count = loaded if loaded is not None else (0, 0)
+        hip.check(self._lib.rcfm_tuner_attach_spectrum(self._device_tuner(int(n)), hip.ptr(slot), int(first), int(count)))
+        self._slot = slot          # keeps the storage alive while the handle points at it
+        self._loaded_size = int(n) if loaded is not None else None
+
+    def window(self, n, first, count):
+        """(first_bin, nbins): the bins of an n-point spectrum that channels [first, first + count) read, modulo n."""
+        fb, nb = ctypes.c_int64(), ctypes.c_int64()
+        hip.check(self._lib.rcfm_tuner_window(self._device_tuner(int(n)), int(first), int(count), ctypes.byref(fb),
+                                              ctypes.byref(nb)))
+        return int(fb.value), int(nb.value)
+
+    def adopt(self, n, first, count):
+        """The caller has written window(n, first, count) into the attached slot: accept it as loaded."""
+        hip.check(self._lib.rcfm_tuner_adopt(self._device_tuner(int(n)), int(first), int(count), hip.stream()))
+        self._loaded_size = int(n)
 
     def _ready(self):
         if self._loaded_size is None:

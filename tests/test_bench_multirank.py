@@ -26,11 +26,12 @@ def _free_port():
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_dry_run_prints_one_contract_line():
+@pytest.mark.parametrize("parallelism", ["replicated", "rotating"])
+def test_two_rank_dry_run_prints_one_contract_line(parallelism):
     env = dict(os.environ, RCFM_BENCH_DEVICE="0", RCFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--config", "small"]
+           "--warmup", "1", "--config", "small", "--parallelism", parallelism]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -42,6 +43,14 @@ def test_two_rank_dry_run_prints_one_contract_line():
     assert abs(r["value"] - r["config"]["wideband_samples"] / (r["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * r["value"]
     assert r["roofline"]["traffic"] is None                          # the committed PMC passes describe one GPU
     assert r["cpu_baseline"] is None                                 # rank 0 at N = 1 only
-    assert r["channel_stage_value"]["value"] > 0 and 1.0 < r["amdahl_bound_speedup"] < 2.0
+    assert r["channel_stage_value"]["value"] > 0
+    assert r["pcie_inclusive"]["value"] > 0                          # the N > 1 line always carries the host-fed rate
+    if parallelism == "rotating":
+        assert r["amdahl_bound_speedup"] == 2.0 and "rotating FFT owner" in r["config"]["parallelism"]
+        ro = r["rotating_owner"]
+        assert ro["lookahead"] == 2 and ro["spectrum_slots"] == 3 and ro["ffts_per_rank_per_buffer"] == 0.5
+        assert 0 < ro["bytes_sent_per_owned_buffer"] <= 8 * r["config"]["wideband_samples"]
+    else:
+        assert 1.0 < r["amdahl_bound_speedup"] < 2.0
     g = r["gather_check"]
     assert g["finite"] and g["own_block_equal"] and g["blocks_with_audio"] == g["blocks"] == 2

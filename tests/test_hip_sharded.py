@@ -110,6 +110,63 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path, kind, C, exact):
                 assert rel_err(got[b][c], want[c]) <= 0.05 * TOL, (kind, b, c)
 
 
+def _ring_worker(rank, world, port, kind, C, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    _paths()
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    import radiocore as rc
+    from radiocore.tools import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    centres, bufs = _inputs(kind, C)
+    bufs = bufs + [np.roll(bufs[0], 17), np.roll(bufs[1], 29), bufs[0] * np.float32(0.5)]      # 5 buffers
+    lo, hi = sharding.channel_range(rank, world, C)
+    tuner = _tuner(rc, kind, centres)
+    ring = sharding.SpectrumRing(tuner, N, C)
+    dev = [torch.from_numpy(b).cuda() for b in bufs]
+    gathered = []
+    for j in range(min(ring.lookahead, len(bufs))):
+        ring.submit(j, dev[j] if ring.owner(j) == rank else None)
+    for i in range(len(bufs)):
+        j = i + ring.lookahead
+        if j < len(bufs):
+            # buffer j of an owner may also arrive from the HOST (page-locked or not): the ring stages it
+            src = torch.from_numpy(bufs[j]) if j == 3 else dev[j]
+            ring.submit(j, src if ring.owner(j) == rank else None)
+        ring.acquire(i)
+        block = tuner.run_all()
+        assert block.shape[0] == hi - lo
+        gathered.append(sharding.gather_audio(torch.from_numpy(block), C, dst=0))
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.stack([g.numpy() for g in gathered]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,C", [("WBFM", 8), ("MFM", 8)])
+def test_rotating_fft_owner_equals_single_process(tmp_path, kind, C):
+    """sharding.SpectrumRing with the real tuner: two ranks on one GPU take turns running the wideband FFT; the rank
+    that did not run it receives only the bins its channels read (rcfm_tuner_window / _attach_spectrum / _adopt) and
+    must produce bit-identical audio -- five buffers, two in flight, state carried per channel."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ring.npy")
+    mp.spawn(_ring_worker, args=(2, _free_port(), kind, C, out), nprocs=2, join=True)
+    got = np.load(out)
+    _paths()
+    import radiocore as rc
+    centres, bufs = _inputs(kind, C)
+    bufs = bufs + [np.roll(bufs[0], 17), np.roll(bufs[1], 29), bufs[0] * np.float32(0.5)]
+    tuner = _tuner(rc, kind, centres)
+    for b, x in enumerate(bufs):
+        tuner.load(x)
+        want = tuner.run_all()
+        assert np.array_equal(got[b], want), (kind, b, float(np.max(np.abs(got[b] - want))))
+
+
 def test_c_abi_gather_world_of_one():
     """rcfm_comm_* / rcfm_gather_audio (RCCL bound at run time): the degenerate one-rank communicator on this
     GPU -- unique id, init, a gather that must reproduce the block, destroy.  (RCCL refuses two ranks on one

@@ -1,0 +1,150 @@
+"""CPU, world_size 2 and 3, gloo: the rotating-FFT-owner protocol (radiocore.tools.sharding.SpectrumRing).
+
+The library's tuner is replaced by a stand-in with the same six methods (window / spectrum_slot / attach / load /
+adopt / shard) on host tensors, so the schedule, the ownership rotation, the window bookkeeping (wrapping windows,
+halos) and the point-to-point message order run here without a GPU; tests/test_hip_sharded.py runs the real tuner
+through the same class on one GPU.  What is asserted: on every rank and for every buffer, the bins its channels read
+are exactly those of the FFT of THAT buffer, whoever computed it, while `lookahead` later buffers are in flight.
+
+Reference: one process does everything (examples/multi_fm_server.py:95-106); nothing there to cite for the protocol."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+N, C, HALO, ROW = 4096, 7, 64, 32
+# channel c reads bins [centre - 40, centre + 40] modulo N; the first one wraps around bin 0
+CENTRES = [10, 600, 1200, 1800, 2400, 3000, 3900]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class FakeTuner:
+    """Host stand-in for radiocore.tools.Tuner's spectrum interface."""
+
+    def __init__(self):
+        self.slot = None
+        self.loaded = None
+        self.shard_range = None
+        self.loads = 0
+
+    def shard(self, first, count):
+        self.shard_range = (first, count)
+
+    def window(self, n, first, count):
+        rows = n // ROW
+        used = np.zeros(rows, bool)
+        for c in range(first, first + count):
+            for b in range(CENTRES[c] - 40, CENTRES[c] + 41):
+                used[(b % n) // ROW] = True
+        # everything but the longest circular run of unused rows (api.hip: rcfm_tuner_s::row_window)
+        best, start, run = 0, 0, 0
+        for i in range(2 * rows):
+            if not used[i % rows]:
+                run += 1
+                if run > best and run <= rows:
+                    best, start = run, i - run + 1
+            else:
+                run = 0
+        if best == 0 or best >= rows:
+            return 0, n
+        lo, hi = (start + best) % rows, (start - 1) % rows
+        return lo * ROW, ((hi - lo) % rows + 1) * ROW
+
+    def spectrum_slot(self, n):
+        t = torch.full((n + 2 * HALO,), complex(np.nan, np.nan), dtype=torch.complex64)
+        t.rcfm_halo = HALO
+        return t
+
+    def attach(self, slot, n, loaded=None):
+        self.slot, self.loaded = slot, loaded
+
+    def load(self, x, whole=False):
+        assert whole
+        self.loads += 1
+        X = torch.fft.fft(x)
+        self.slot[HALO:HALO + N] = X
+        self.slot[:HALO] = X[-HALO:]
+        self.slot[HALO + N:] = X[:HALO]
+        self.loaded = (0, C)
+
+    def adopt(self, n, first, count):
+        s = self.slot
+        s[:HALO] = s[N:N + HALO]                 # (the real adopt copies only the window's part: NaN stays NaN elsewhere)
+        s[HALO + N:] = s[HALO:2 * HALO]
+        self.loaded = (first, count)
+
+    def read(self, c):
+        assert self.loaded[0] <= c < self.loaded[0] + self.loaded[1]
+        idx = HALO + CENTRES[c] + torch.arange(-40, 41)          # through the halo, no modulo: like the gather kernel
+        return self.slot[idx]
+
+
+def _buffer(i):
+    g = torch.Generator().manual_seed(100 + i)
+    return torch.complex(torch.randn(N, generator=g), torch.randn(N, generator=g)).to(torch.complex64)
+
+
+def _worker(rank, world, port, lookahead, buffers, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
+    from radiocore.tools import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tuner = FakeTuner()
+    ring = sharding.SpectrumRing(tuner, N, C, lookahead=lookahead)
+    lo, hi = sharding.channel_range(rank, world, C)
+    assert tuner.shard_range == (lo, hi - lo)
+    ok = True
+    with pytest.raises(RuntimeError, match="after their submit"):
+        ring.acquire(0)
+    for j in range(min(ring.lookahead, buffers)):                 # prime
+        ring.submit(j, _buffer(j) if ring.owner(j) == rank else None)
+    for i in range(buffers):
+        if i + ring.lookahead < buffers:
+            j = i + ring.lookahead
+            ring.submit(j, _buffer(j) if ring.owner(j) == rank else None)
+        ring.acquire(i)
+        want = torch.fft.fft(_buffer(i))
+        for c in range(lo, hi):
+            got = tuner.read(c)
+            ref = want[(CENTRES[c] + torch.arange(-40, 41)) % N]
+            ok = ok and bool(torch.equal(got, ref))
+    with pytest.raises(RuntimeError, match="in order"):
+        ring.submit(buffers + 5)
+    owned = len([i for i in range(buffers) if i % world == rank])
+    ok = ok and tuner.loads == owned                               # one FFT per owned buffer, none for the others
+    dist.barrier()
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(ok), ring.bytes_sent_per_buffer()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lookahead", [(2, None), (2, 1), (3, None), (3, 5)])
+def test_rotating_owner_delivers_every_window(tmp_path, world, lookahead):
+    mp.spawn(_worker, args=(world, _free_port(), lookahead, 9, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, sent = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
+        assert ok == 1, r
+        assert 0 < sent < 8 * N * (world - 1)                      # windows, not whole spectra
+
+
+def test_window_segments():
+    sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
+    from radiocore.tools.sharding import window_segments
+    assert window_segments(10, 5, 20) == [(10, 15)]
+    assert window_segments(18, 5, 20) == [(18, 20), (0, 3)]
+    assert window_segments(0, 20, 20) == [(0, 20)] and window_segments(7, 25, 20) == [(0, 20)]
