@@ -15,6 +15,7 @@
 
 #include "lds_chain.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -98,10 +99,8 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     __shared__ __attribute__((aligned(16))) float2 xs[B];
     __shared__ __attribute__((aligned(16))) float ds[B];
     float* const th1 = reinterpret_cast<float*>(xs) + B;      // member 1's phases: upper half of xs
-    const int tid = threadIdx.x;
-    const int c0 = 2 * (int)blockIdx.x;
-    const bool has1 = c0 + 1 < p.a.count;
-    const int c1 = has1 ? c0 + 1 : c0;
+    int tid = threadIdx.x;
+    const int npairs = (p.a.count + 1) / 2;
     constexpr int NL = (B + T - 1) / T;
 
     auto window = [&](int d) -> float {
@@ -109,26 +108,41 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         const float t = th * th;
         return fmaf(t, fmaf(t, fmaf(t, p.c3, p.c2), p.c1), p.c0);
     };
-
-    // ---- the two channels: gather -> IFFT_B -> phases --------------------------------------------------------
-#pragma unroll 1
-    for (int mem = 0; mem < 2; ++mem) {
-        RCFM_TRACE_POINT(mem * 6 + 0);
-        const float2* Xc = p.a.X + p.a.base[mem ? c1 : c0];
-        float2 v[NL];
+    // The B bins of one channel, raw, into registers: issued one phase AHEAD of their use (the member's loads fly
+    // under the previous member's arctangents, the next pair's under this pair's IFFT_A) -- with one workgroup per CU
+    // nothing else would hide the memory latency.
+    float2 v[NL], x2;
+    auto issue_gather = [&](int c) {
+        const float2* Xc = p.a.X + p.a.base[c];
 #pragma unroll
         for (int it = 0; it < NL; ++it) {
             int k = tid + T * it;
             k = k < B ? k : B - 1;                              // ragged last sweep: clamped, not stored
             v[it] = Xc[k < p.a.nyq ? k : k - B];
         }
-        float2 m2 = make_float2(0.f, 0.f);                      // Y[+B/2] += X[-B/2] w(-B/2) (NYQ_DOWN)
+        x2 = Xc[p.a.merge >= 0 ? -p.a.merge : 0];               // Y[+B/2] += X[-B/2] w(-B/2) (NYQ_DOWN)
+    };
+
+    int pair = (int)blockIdx.x;
+    if (pair < npairs) issue_gather(2 * pair);
+#pragma unroll 1
+    for (; pair < npairs; pair += (int)gridDim.x) {
+    asm volatile("" : "+v"(tid));      // per-thread index tables stay inside the iteration (they would cost the registers
+                                       // the butterflies need: fft_kernel.h, persistent form)
+    const int c0 = 2 * pair;
+    const bool has1 = c0 + 1 < p.a.count;
+    const int c1 = has1 ? c0 + 1 : c0;
+
+    // ---- the two channels: gather -> IFFT_B -> phases --------------------------------------------------------
+    auto member = [&](auto MEM) {                               // (straight-line for both members: no conditional
+        constexpr int mem = decltype(MEM)::value;               //  definition keeps the prefetched bins alive longer)
+        RCFM_TRACE_POINT(mem * 6 + 0);
+        float2 m2 = make_float2(0.f, 0.f);
         if (p.a.merge >= 0) {
-            const float2 x2 = Xc[-p.a.merge];
             const float w2 = window(-p.a.merge);
             m2 = make_float2(x2.x * w2, x2.y * w2);
         }
-        if (mem) lds_barrier();                                 // member 0's last stage has read all of xs
+        // (xs is free: member 0 starts behind the previous pair's closing barrier, member 1 behind the one below)
 #pragma unroll
         for (int it = 0; it < NL; ++it) {
             const int k = tid + T * it;
@@ -148,7 +162,8 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         RCFM_TRACE_POINT(mem * 6 + 3);
         float2 y[R2];
         const int kb = chain_last<B, R0, R1, R2, T>(xs, tid, y);
-        if (mem) lds_barrier();                                 // th1 overlays xs: every read of xs is done
+        if constexpr (mem == 0) issue_gather(c1);               // member 1's bins fly under member 0's arctangents
+        lds_barrier();                                          // every read of xs is done (th1 overlays it; member 1 refills it)
         RCFM_TRACE_POINT(mem * 6 + 4);
         if (tid < B / R2) {
             float* dst = mem ? th1 : ds;
@@ -159,27 +174,34 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
             }
         }
         RCFM_TRACE_POINT(mem * 6 + 5);
-    }
+    };
+    member(std::integral_constant<int, 0>{});
+    member(std::integral_constant<int, 1>{});
     lds_barrier();
     RCFM_TRACE_POINT(12);
 
     // ---- u[t] = d0[t] + j d1[t]: the wrapped phase steps of both channels (fm.py:60-65) ---------------------------
+    // two adjacent samples per thread: theta[t0 - 1] and the aligned pair (theta[t0], theta[t0 + 1]) of each member,
+    // one 16-byte store of (u[t0], u[t0 + 1])
     {
-        float2 u[NL];
+        static_assert(B % 2 == 0, "pairs of samples");
+        constexpr int NP = (B / 2 + T - 1) / T;
+        float4 u[NP];
 #pragma unroll
-        for (int it = 0; it < NL; ++it) {
-            int t = tid + T * it;
-            t = t < B ? t : B - 1;
-            const int tp = t > 0 ? t - 1 : 0;
-            const float d0 = phase_step_wrapped(ds[t], ds[tp]);
-            const float d1 = phase_step_wrapped(th1[t], th1[tp]);
-            u[it] = t > 0 ? make_float2(d0, d1) : make_float2(0.f, 0.f);
+        for (int it = 0; it < NP; ++it) {
+            int t0 = 2 * (tid + T * it);
+            t0 = t0 < B ? t0 : B - 2;
+            const float2 a = *reinterpret_cast<const float2*>(&ds[t0]);
+            const float2 b = *reinterpret_cast<const float2*>(&th1[t0]);
+            const float ap = ds[t0 > 0 ? t0 - 1 : 0], bp = th1[t0 > 0 ? t0 - 1 : 0];
+            u[it] = make_float4(t0 > 0 ? phase_step_wrapped(a.x, ap) : 0.f, t0 > 0 ? phase_step_wrapped(b.x, bp) : 0.f,
+                                phase_step_wrapped(a.y, a.x), phase_step_wrapped(b.y, b.x));
         }
         lds_barrier();                                          // th1 is overwritten below, ds is free from here
 #pragma unroll
-        for (int it = 0; it < NL; ++it) {
-            const int t = tid + T * it;
-            if (t < B) xs[t] = u[it];
+        for (int it = 0; it < NP; ++it) {
+            const int t0 = 2 * (tid + T * it);
+            if (t0 < B) *reinterpret_cast<float4*>(&xs[t0]) = u[it];
         }
     }
     // The decimation's weights (A/2 + 1 folded Hamming values times 1/B) go to ds now: their global loads fly under
@@ -244,6 +266,9 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         const float2 a = xs[A / 2], b = xs[A];
         xs[A / 2] = make_float2(a.x + b.x, a.y + b.y);
     }
+    // the next pair's first member: under IFFT_A (the last pair re-reads its own bins -- an unconditional definition
+    // is what lets the registers of the previous gather go)
+    issue_gather(2 * (pair + (int)gridDim.x < npairs ? pair + (int)gridDim.x : pair));
     lds_barrier();
 
     // ---- IFFT_A: real part -> member 0, imaginary part -> member 1 -----------------------------------------------
@@ -281,6 +306,8 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         }
     }
     RCFM_TRACE_POINT(21);
+    lds_barrier();                                              // the next pair refills xs
+    }   // pairs of this workgroup
 }
 
 // (B; R0, R1, R2 | A; Q0, Q1, Q2 | threads): each stage has at most `threads` butterflies.
@@ -359,7 +386,10 @@ bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream
     p.c3 = (float)(-a1 / 720.0);
     p.twB = twiddle_table(B);
     p.twA = twiddle_table(A);
-    const dim3 grid((unsigned)((args.count + 1) / 2));
+    // one workgroup per CU is all the LDS allows: as many workgroups as CUs, each walking its pairs (the next pair's
+    // bins are fetched under the current pair's last transform)
+    const unsigned pairs = (unsigned)((args.count + 1) / 2);
+    const dim3 grid(std::min<unsigned>(pairs, (unsigned)FftEngine::compute_units()));
 #define RCFM_CASE(B_, R0, R1, R2, A_, Q0, Q1, Q2, T_)                                                        \
     if (B == B_ && A == A_) {                                                                                \
         hipLaunchKernelGGL((k_fm_lds<B_, R0, R1, R2, A_, Q0, Q1, Q2, T_>), grid, dim3(T_), 0, stream, p);   \
