@@ -1073,6 +1073,10 @@ int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, 
         RC_REQUIRE(loaded_count <= 0 || (loaded_first >= 0 && loaded_first + loaded_count <= t->nch), RCFM_ERR_INDEX,
                    "channel index out of range");
         t->ext = static_cast<float2*>(storage);
+        // the handle's own [halo | n | halo] buffer is not needed while the caller supplies the storage
+        const size_t own_bytes = sizeof(float2) * (size_t)(t->n + 2 * t->halo);
+        if (storage != nullptr) t->X.reset(0);
+        else if (t->X.bytes() < own_bytes) t->X.reset(own_bytes);
         // what the storage holds: the bins of channels [loaded_first, loaded_first + loaded_count), or nothing yet
         t->loaded = loaded_count > 0;
         int64_t fb = 0, nb = t->n;

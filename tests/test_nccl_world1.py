@@ -83,14 +83,16 @@ def test_gather_audio_on_a_one_rank_rccl_group(tmp_path):
 
 
 @pytest.mark.timeout(900)
-def test_bench_one_rank_through_the_rccl_code_path():
+@pytest.mark.parametrize("parallelism", ["replicated", "rotating"])
+def test_bench_one_rank_through_the_rccl_code_path(parallelism):
     """bench.py --gpus 1 launched by torch.distributed.run exactly as the driver launches N > 1, forced down the
-    N > 1 branches (RCFM_BENCH_FORCE_DIST=1) on the nccl backend."""
+    N > 1 branches (RCFM_BENCH_FORCE_DIST=1) on the nccl backend; `rotating` adds the spectrum ring (slots, the owner's
+    FFT on its own stream, attach / adopt) -- with one rank every buffer is its own, so no transfer is posted."""
     env = dict(os.environ, RCFM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RCFM_BENCH_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4",
-           "--warmup", "1", "--config", "small", "--cpu-channels", "0", "--no-extras"]
+           "--warmup", "1", "--config", "small", "--cpu-channels", "0", "--no-extras", "--parallelism", parallelism]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
