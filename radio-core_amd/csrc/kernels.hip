@@ -7,6 +7,8 @@
 // scipy calls) is derived in DESIGN.md and pinned by tests/test_oracle_scipy.py.
 
 #include "kernels.h"
+
+#include <cmath>
 // RCFM_ABLATE & 16 (timing experiments only, wrong results; fft_kernel.h lists the bits): no taps in the pilot FIR
 #ifdef RCFM_ABLATE
 #define RCFM_ABLATE_K RCFM_ABLATE
@@ -642,39 +644,60 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
         mean = tot / (float)total;
     }
     const int o = tid * PER;
-    // y[e0 + r] = sum_j b[j] z[e0 + r - CH j]: tap j reads the 8-value span that starts CH j below the outputs, so
-    // the span slides down by CH values per tap.  It lives in a circular register buffer of 8 + 2 CH values whose
-    // slot numbers are compile-time constants (the loop is fully unrolled: no register moves); the CH values the
-    // next tap adds are read from LDS one tap ahead.  ~30 VGPRs instead of the 108-value window: twice the waves.
-    constexpr int RB = PER + 2 * CH;                                // ring size; value at offset d sits in slot d mod RB
-    auto slot = [](int d) -> int { return ((d % RB) + RB) % RB; };
-    float ring[RB];
-    auto fill = [&](int d) {                                        // loads values d .. d + CH - 1 (relative to e0)
-        if constexpr (CH == 2) {
-            v2f q = *reinterpret_cast<const v2f*>(&x_s[xpos(o + HP + d)]);   // d even: the pair never crosses a pad
-            asm volatile("" : "+v"(q));
-            ring[slot(d)] = q.x;
-            ring[slot(d + 1)] = q.y;
-        } else {
-            float q = x_s[xpos(o + HP + d)];
-            asm volatile("" : "+v"(q));
-            ring[slot(d)] = q;
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < PER; d += CH) fill(d);                      // the span of tap 0
-    fill(-CH);                                                      // ... and what tap 1 adds
+    const int64_t e0 = t0 + o;
+    // y[e] = sum_j b[j] z[e - CH j], and the 51 taps are the first samples of a one-pole impulse response:
+    // b[0] = 0, b[j] = c x^(j-1) (deemphasis.py:37-46).  A truncated geometric series obeys
+    //     y[e] = x y[e - CH] + b[1] z[e - CH] - x b[50] z[e - 51 CH],
+    // so only the first sample of each leg in a thread's run of 8 outputs takes the 51-tap sum (one 8-byte LDS read and
+    // CH FMAs per tap); the other 8 - CH follow in three FMAs each: 15 instead of 51 FMAs per output, and the kernel
+    // is no longer bound by the VALU (cfg4: 0.228 -> 0.18-0.20 ms).  Rounding: the recursion runs for
+    // at most 8 / CH - 1 steps before the next full sum; against the float64 sum it is as close as the plain float32
+    // FIR (3.9e-7 of peak either way).  Threads whose outputs still see the carried-in state (e0 < HIST) take the plain
+    // sums: their recursion would need inputs of the previous buffer, of which only the state survives.
+    auto zl = [&](int d) -> float { return x_s[xpos(o + HP + d)]; };   // z[e0 + d], d >= -HP (zero outside the signal)
     float acc[PER];
+    if (e0 >= HIST) {
+        // (the tap sum is split over independent partial sums: one accumulator would be a chain of 50 dependent FMAs)
+        constexpr int NP = 4 / CH;
+        float part[CH][NP];
 #pragma unroll
-    for (int r = 0; r < PER; ++r) acc[r] = 0.f;
+        for (int r = 0; r < CH; ++r)
 #pragma unroll
-    for (int j = 0; j <= 50; ++j) {
-        if (j + 2 <= 50) fill(-CH * (j + 2));                       // two taps ahead: its slots were freed by tap j - 1 ...
+            for (int i = 0; i < NP; ++i) part[r][i] = 0.f;
 #pragma unroll
-        for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], ring[slot(r - CH * j)], acc[r]);
+        for (int j = 1; j <= 50; ++j) {
+            if constexpr (CH == 2) {
+                v2f q = *reinterpret_cast<const v2f*>(&x_s[xpos(o + HP - 2 * j)]);   // even offset: one aligned pair
+                part[0][j % NP] = fmaf(taps.b[j], q.x, part[0][j % NP]);
+                part[1][j % NP] = fmaf(taps.b[j], q.y, part[1][j % NP]);
+            } else {
+                part[0][j % NP] = fmaf(taps.b[j], zl(-j), part[0][j % NP]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            float a = part[r][0];
+#pragma unroll
+            for (int i = 1; i < NP; ++i) a += part[r][i];
+            acc[r] = a;
+        }
+        const float xr = taps.b[2] / taps.b[1];                      // (uniform: scalar unit)
+        const float tail = xr * taps.b[50];
+#pragma unroll
+        for (int r = CH; r < PER; ++r)
+            acc[r] = fmaf(xr, acc[r - CH], fmaf(taps.b[1], zl(r - CH), -tail * zl(r - 51 * CH)));
+    } else {
+        // (eight independent sums, taps in the outer loop: this path is on the critical path of short launches --
+        //  one wave per signal takes it, and a launch of 1.2 rounds of workgroups waits for exactly that wave)
+#pragma unroll
+        for (int r = 0; r < PER; ++r) acc[r] = 0.f;
+#pragma unroll 5
+        for (int j = 1; j <= 50; ++j) {
+#pragma unroll
+            for (int r = 0; r < PER; ++r) acc[r] = fmaf(taps.b[j], zl(r - CH * j), acc[r]);
+        }
     }
     float local = 0.f;
-    const int64_t e0 = t0 + o;
     if (e0 < HIST) {                                               // lfilter's initial conditions
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
@@ -896,6 +919,13 @@ void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const 
     if (batch <= 0 || n <= 0) return;
     DeemphTaps taps;
     for (int i = 0; i < 51; ++i) taps.b[i] = taps_host[i];
+    // k_fir51 runs the one-pole recursion between full tap sums: the taps must be what deemphasis.py:37-46 designs,
+    // b[0] = 0 and a geometric tail
+    RC_REQUIRE(taps.b[0] == 0.f && taps.b[1] > 0.f, RCFM_ERR_RUNTIME, "de-emphasis taps are not a one-pole response");
+    for (int i = 1; i < 50; ++i)   // (in double, with a floor: fast-decaying responses end in denormals and zeros)
+        RC_REQUIRE(std::fabs((double)taps.b[i + 1] * taps.b[1] - (double)taps.b[i] * taps.b[2]) <=
+                       4e-7 * (double)taps.b[i] * taps.b[1] + 1e-36,
+                   RCFM_ERR_RUNTIME, "de-emphasis taps are not a one-pole response");
     const RowLayout lay = row_layout(n, ch, row_samples, row_pitch_samples);
     const dim3 grid((unsigned)fir51_tiles(n, ch), (unsigned)batch, 1);
     if (ch == 2)
