@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1575,6 +1576,12 @@ struct StoreRowWindow {
     }
 };
 
+}  // namespace fftk
+}  // namespace rcfm
+#include "fft_dma.h"
+namespace rcfm {
+namespace fftk {
+
 // Lengths with a compile-time specialisation (radices listed first stage first; they must
 // match choose_radices() in fft_engine.hip).  Other lengths run the generic kernel.
 // RCFM_FFT_TWO_STAGE: the 480..640-point tiles as two LDS stages of composite radices (dft_nat).
@@ -1680,10 +1687,66 @@ inline bool getenv_fft_persist() {
     return v;
 }
 
+// RCFM_FFT_DMA (environment, read once): 1 = the streaming passes over big tiles load by LDS-DMA into two LDS buffers
+// (k_fft_tile_dma, one persistent workgroup per CU), 0 = k_fft_tile (two workgroups per CU, loads through VGPRs).
+#ifndef RCFM_FFT_DMA_DEFAULT
+#define RCFM_FFT_DMA_DEFAULT 0
+#endif
+inline bool getenv_fft_dma() {
+    static const bool v = [] {
+        const char* e = std::getenv("RCFM_FFT_DMA");
+        return e ? e[0] != '0' : RCFM_FFT_DMA_DEFAULT != 0;
+    }();
+    return v;
+}
+template <class T> struct plain_load_swap;
+template <bool S> struct plain_load_swap<LoadPlainT<S>> { static constexpr bool value = S; };
+template <class T> struct is_plain_store : std::false_type {};
+template <bool S> struct is_plain_store<StorePlainT<S>> : std::true_type {};
+
+// The DMA form applies when every 16-byte piece it fetches is aligned and inside the input: strided passes with whole
+// tiles (n_inner a multiple of 16) and even strides, rows passes whose lines are a multiple of 8 points at an even pitch.
+template <int LEN, bool ROWS>
+inline bool fft_dma_applies(const FftPassDev& d, dim3 grid, const float2* in) {
+    if (!getenv_fft_dma() || (reinterpret_cast<uintptr_t>(in) & 15u)) return false;
+    const FftPass& p = d.p;
+    const unsigned total = grid.x * grid.y * grid.z;
+    if (total < 2u * (unsigned)FftEngine::compute_units()) return false;   // nothing to pipeline
+    if ((d.in_batch | p.in_o1 | p.in_o2) & 1) return false;
+    if (ROWS) return LEN % 8 == 0 && (p.in_i & 1) == 0;
+    return p.n_inner % W == 0 && (p.in_l & 1) == 0 && p.in_i == 1;
+}
+
 template <int LEN, int A, int B, int C, int D, bool ROWS, class LoadOp, class StoreOp>
 inline void launch_fft_tile_one(const FftPassDev& d, dim3 grid, const LoadOp& ld, const StoreOp& st, hipStream_t s) {
     constexpr int T = tile_threads(LEN);
     constexpr bool kResidentTile = big_tile_pair(LEN) || triple_tile(LEN);
+    if constexpr (big_tile_pair(LEN) && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value &&
+                  (!ROWS || LEN % 8 == 0)) {
+        if (fft_dma_applies<LEN, ROWS>(d, grid, ld.in)) {
+            const unsigned cus = (unsigned)FftEngine::compute_units() & ~7u;
+            hipLaunchKernelGGL((k_fft_tile_dma<LEN, A, B, C, D, ROWS, plain_load_swap<LoadOp>::value, StoreOp,
+                                               is_plain_store<StoreOp>::value>),
+                               dim3(cus), dim3(1024), 0, s, d, ld.in, st, grid);
+#ifdef RCFM_DMA_TRACE
+            {
+                static int shots = 0;
+                if (shots++ < 6) {
+                    long long t[32 * 8];
+                    (void)hipStreamSynchronize(s);
+                    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_dma_trace), sizeof(t));
+                    std::printf("k_fft_tile_dma<%d,%s> ticks per phase of workgroup 0 (wait+barrier, issue, stage 1, stage 2, stage 3, last stage; then the gap to the next tile)\n", LEN, ROWS ? "rows" : "strided");
+                    for (int i = 0; i < 24; ++i) {
+                        std::printf("  tile %2d:", i);
+                        for (int k = 0; k < 6; ++k) std::printf(" %6lld", t[i * 8 + k + 1] - t[i * 8 + k]);
+                        std::printf("   total %6lld\n", t[i * 8 + 6] - t[i * 8]);
+                    }
+                }
+            }
+#endif
+            return;
+        }
+    }
     if constexpr (RCFM_FFT_PERSIST && kResidentTile && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
         // streaming passes of long transforms: as many workgroups as the chip holds at once, each walking its tiles
         const unsigned resident = (unsigned)((big_tile_pair(LEN) ? 2 : 3) * FftEngine::compute_units());
