@@ -140,6 +140,18 @@ int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_hos
  * `single` may itself hold several channels (slots [index, index + its C) are taken: two batched handles of one
  * geometry then share one state).  Same class, audio rate and time constant required; FM has no state (no-op). */
 int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, int move_history, void* stream);
+/* Which forms of the chain a handle may use (no reference counterpart: the reference has one form of everything).
+ * All default to 1.  The results do not depend on them beyond float32 rounding -- tests/test_hip_configs.py compares
+ * every channel of a full-size buffer between the default handle and one with all three switched off, which shares no
+ * kernel schedule with it.
+ *   RCFM_OPT_LDS_CHAIN    narrow FM / MFM channels run tuner + demodulator of a channel pair in one workgroup (0: the
+ *                         multi-pass launches)
+ *   RCFM_OPT_FUSED_TILES  two transforms per tile: pilot chain, Hilbert mask, stereo mix, spectral decimation between
+ *                         transforms (0: one transform per launch, the intermediate spectra go through memory)
+ *   RCFM_OPT_PHASE_LINK   the tuner hands the demodulator angle(x) / pi as float32 (0: complex64 samples, as
+ *                         tuner.py:161 returns them) */
+enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3 };
+int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 
 /* Whole hot path for one wideband buffer already loaded with rcfm_tuner_load:

@@ -442,6 +442,11 @@ struct rcfm_tuner_s {
     }
 };
 
+static bool env_default_on(const char* name) {
+    const char* e = std::getenv(name);
+    return !(e && e[0] == '0');
+}
+
 struct rcfm_demod_s {
     int kind = 0, C = 0, B = 0, A = 0, ch = 1, chunk = 1;
     double tau = 75e-6;
@@ -464,6 +469,12 @@ struct rcfm_demod_s {
     std::unique_ptr<FftEngine> eng_Ad;         // length A as (A / n_1, n_1): its first pass tiles like eng_B's last
     std::unique_ptr<FftEngine> eng_Bi;         // eng_B's two pass lengths swapped (k_fft_tile2 pairing)
     DeviceBuffer buf_Ti;
+    // rcfm_demod_set_option: which forms of the chain rcfm_pipeline_run / run_chunk may use.  The defaults come from
+    // the RCFM_* environment switches (A/B tooling, read once per process); parity tests flip them per handle to get a
+    // second evaluation that shares no kernel schedule with the default one.
+    bool opt_lds_chain = env_default_on("RCFM_LDS_CHAIN");
+    bool opt_fused_tiles = env_default_on("RCFM_PILOT_CHAIN") && env_default_on("RCFM_DECIM_TILE");
+    bool opt_phase_link = env_default_on("RCFM_PHASE_LINK");
     DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2, buf_dc;
     int tiles = 0;
 
@@ -611,12 +622,9 @@ struct rcfm_demod_s {
                 // RCFM_PILOT_CHAIN=0: pair FFT -> U2 -> masked IFFT as separate transforms; RCFM_HILBERT_UNPACK=1:
                 // additionally one inverse FFT per channel (A/B testing of the fused forms)
                 static const bool unpacked = std::getenv("RCFM_HILBERT_UNPACK") != nullptr;
-                static const bool no_chain = [] {
-                    const char* e = std::getenv("RCFM_PILOT_CHAIN");
-                    return e && e[0] == '0';
-                }();
+                const bool no_chain = !opt_fused_tiles;
                 const bool chain = eng_Bi && !unpacked && !no_chain && fused_pilot_chain_applies(*eng_B, *eng_Bi, cnt);
-                const bool packed = eng_Bi && !unpacked && fused_hilbert_packed_applies(*eng_Bi, *eng_B, cnt);
+                const bool packed = eng_Bi && opt_fused_tiles && !unpacked && fused_hilbert_packed_applies(*eng_Bi, *eng_B, cnt);
                 bool paired = false;
                 if (chain) {
                     {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
@@ -633,7 +641,7 @@ struct rcfm_demod_s {
                         StageTimer tm(ST_FFT_REAL_B, s);
                         fused_real_pair_fft(*eng_B, p, U2, T, cnt, packed ? kKeepLowerHalf : -1, s);
                     }
-                    if (eng_Bi) {
+                    if (eng_Bi && opt_fused_tiles) {
                         // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
                         // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
                         StageTimer tm(ST_IFFT_B, s);
@@ -642,10 +650,7 @@ struct rcfm_demod_s {
                                                                              buf_Ti.as<float2>(), T, cnt, s);
                     }
                 }
-                static const bool no_decim = [] {
-                    const char* e = std::getenv("RCFM_DECIM_TILE");
-                    return e && e[0] == '0';
-                }();
+                const bool no_decim = !opt_fused_tiles;
                 if (paired && eng_Ad && !no_decim && fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, cnt)) {
                     const int pitch = audio_pitch();
                     {   // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
@@ -735,10 +740,7 @@ struct rcfm_demod_s {
             StageTimer tm(ST_DISC, s);
             launch_discriminator(iq, d, B, cnt, s);
         }
-        static const bool no_decim_pairs = [] {
-            const char* e = std::getenv("RCFM_DECIM_TILE");
-            return e && e[0] == '0';
-        }();
+        const bool no_decim_pairs = !opt_fused_tiles;
         if (eng_B && eng_Ad && !no_decim_pairs && ((int64_t)A % 4 == 0 || kind == RCFM_FM) &&
             fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, (cnt + 1) / 2)) {
             // two channels per complex signal from the pair FFT through the decimation to the inverse FFT:
@@ -1221,6 +1223,18 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
     });
 }
 
+int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
+    return guarded([&] {
+        RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");
+        switch (option) {
+            case RCFM_OPT_LDS_CHAIN: d->opt_lds_chain = value != 0; break;
+            case RCFM_OPT_FUSED_TILES: d->opt_fused_tiles = value != 0; break;
+            case RCFM_OPT_PHASE_LINK: d->opt_phase_link = value != 0; break;
+            default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown demodulator option");
+        }
+    });
+}
+
 int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_host) {
     return guarded([&] {
         RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");
@@ -1246,10 +1260,7 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
             // Narrow FM / MFM channels whose whole chain fits the LDS of a CU: gather, IFFT_B, discriminator, FFT_B,
             // decimation and IFFT_A of a channel pair in ONE kernel (lds_chain.h); only the audio reaches memory.
             // RCFM_LDS_CHAIN=0: the multi-pass launches (A/B runs).
-            static const bool no_lds = [] {
-                const char* e = std::getenv("RCFM_LDS_CHAIN");
-                return e && e[0] == '0';
-            }();
+            const bool no_lds = !d->opt_lds_chain;
             if (!no_lds && d->kind != RCFM_WBFM && lds_chain_supported(d->B, d->A) && t->fast_gather_ok(first + off)) {
                 RC_REQUIRE(t->loaded, RCFM_ERR_STATE, "rcfm_pipeline_run called before rcfm_tuner_load");
                 RC_REQUIRE(!t->loaded_windowed || (first + off >= t->loaded_first &&
@@ -1276,10 +1287,7 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
             // Every demodulator starts with the FM discriminator, which only needs the samples' phases:
             // the tuner's last pass leaves angle(x) / pi (float32) instead of x (complex64) -- half the
             // bytes written here and read back by the first demod kernel.  RCFM_PHASE_LINK=0: complex hand-over.
-            static const bool no_phase = [] {
-                const char* e = std::getenv("RCFM_PHASE_LINK");
-                return e && e[0] == '0';
-            }();
+            const bool no_phase = !d->opt_phase_link;
             if (!no_phase && d->phase_capable() && t->phase_capable(first + off)) {
                 // FM / MFM read the phases through LoadPhaseStepPair, which understands padded rows: when the tuner's
                 // last pass would store rows of n_1 phases that are not whole 64-byte segments apart (cfg5: n_1 = 100),

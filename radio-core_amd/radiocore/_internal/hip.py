@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCFM_LIB") or os.path.join(os.path.dirname(_HERE), "_lib", "librcfm.so")
 
 RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
+RCFM_OPT_LDS_CHAIN, RCFM_OPT_FUSED_TILES, RCFM_OPT_PHASE_LINK = 1, 2, 3   # rcfm_demod_set_option
 
 _ERR_SIZE, _ERR_INDEX, _ERR_RUNTIME, _ERR_ARG, _ERR_STATE = -1, -2, -3, -4, -5
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rcfm_demod_set_state": [_vp, _fp, _vp],
     "rcfm_demod_get_taps": [_vp, _fp, _fp],
     "rcfm_demod_bind_state": [_vp, _vp, _i, _i, _vp],
+    "rcfm_demod_set_option": [_vp, _i, _i],
     "rcfm_demod_destroy": [_vp],
     "rcfm_pipeline_run": [_vp, _vp, _i, _i, _vp, _vp],
     "rcfm_host_register": [_vp, _sz],
