@@ -500,6 +500,29 @@ struct rcfm_demod_s {
         if (use_engine() && fft_plan_describe(B, &probe) && fft_plan_describe(A, &probe)) {
             eng_B = std::make_unique<FftEngine>(B);
             eng_A = std::make_unique<FftEngine>(A);
+            // Two-pass plans (n_1, L): the decimation B -> A rides between FFT_B's last pass and IFFT_A's first when
+            // A = n_1 L2 with L2 even (k_fft_tile2_decim); if the planner's order of the two factors does not allow that
+            // and the other order does (256 000 -> 32 000: 512 x 500 gives L2 = 62.5, 500 x 512 gives 64), take the other
+            // one -- the fused chain uses both orders of the plan anyway (eng_Bi below).
+            if (eng_B->npass() == 2 && A < B && !std::getenv("RCFM_FFT_FORCE")) {
+                const FftPlanDesc& pd = eng_B->desc();
+                auto decim_ok = [&](const FftEngine& eb) {
+                    const int64_t n1 = eb.desc().pass[0].L;
+                    const int64_t fa[2] = {A / n1, n1};
+                    FftPlanDesc pa;
+                    if (A % (2 * n1) != 0 || A / n1 < 16 || !fft_plan_describe(A, &pa, 0, fa, 2)) return false;
+                    FftEngine ea(A, fa, 2);
+                    return fused_fft_decim_ifft_applies(eb, ea, 1);
+                };
+                if (!decim_ok(*eng_B)) {
+                    const int64_t swapped[2] = {pd.pass[1].L, pd.pass[0].L};
+                    FftPlanDesc ps;
+                    if (fft_plan_describe(B, &ps, 0, swapped, 2)) {
+                        auto alt = std::make_unique<FftEngine>(B, swapped, 2);
+                        if (decim_ok(*alt)) eng_B = std::move(alt);
+                    }
+                }
+            }
             buf_T.reset(c * eng_B->tmp_stride() * sizeof(float2));
             buf_TA.reset(c * eng_A->tmp_stride() * sizeof(float2));
             if (kind == RCFM_WBFM) {
@@ -517,7 +540,7 @@ struct rcfm_demod_s {
                 const int64_t n1 = pd.pass[0].L;
                 const int64_t fa[2] = {A / n1, n1};
                 FftPlanDesc pa;
-                if (pd.npass == 2 && A < B && A % (2 * n1) == 0 && fft_plan_describe(A, &pa, 0, fa, 2)) {
+                if (pd.npass == 2 && A < B && A % (2 * n1) == 0 && A / n1 >= 16 && fft_plan_describe(A, &pa, 0, fa, 2)) {
                     eng_Ad = std::make_unique<FftEngine>(A, fa, 2);
                     buf_TA.reserve(c * eng_Ad->tmp_stride() * sizeof(float2));
                     if (const int pitch = audio_pitch())   // padded rows of the packed audio

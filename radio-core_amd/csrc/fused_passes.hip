@@ -2,6 +2,7 @@
 #include "device_math.h"
 
 #include "fft_kernel.h"
+#include "fft_decim_rt.h"
 #include "kernels.h"
 
 namespace rcfm {
@@ -424,32 +425,7 @@ struct LoadStereoUnpack {
     }
 };
 
-// decimate.py:48 for the packed stereo pair between FFT_B's last pass and IFFT_A's first pass
-// (k_fft_tile2_decim): u = l + j r is one complex signal and the Hamming weight is real and even, so
-// resampling u resamples both legs: V[kappa] = U[k] W[|kappa|] / B with scipy's Nyquist merge -- no
-// unpacking into L and R at all.
-struct WinAudioDecim {
-    const float* wr;   // folded window, A/2 + 1 entries
-    float2* dc;        // [count] or null: receives V[c][0] = (sum l, sum r) / A
-    float scale;
-    int A, n1;
-    int split_count;   // > 0: the signal is a PAIR of real channels (2P, 2P+1): dc[2P] = (Re, 0), dc[2P+1] = (Im, 0)
-    __device__ __forceinline__ float weight(const LineId&, int l, int k0) const {
-        const int kappa = l * n1 + k0;
-        int kk = kappa <= A / 2 ? kappa : A - kappa;
-        kk = kk < 0 ? 0 : kk;   // rows past the tile's real extent (clamped lanes)
-        return wr[kk] * scale;
-    }
-    __device__ __forceinline__ void dc_bin(const LineId& id, float2 v) const {
-        if (dc == nullptr) return;
-        if (split_count > 0) {
-            dc[2 * id.batch] = make_float2(v.x, 0.f);
-            if (2 * id.batch + 1 < split_count) dc[2 * id.batch + 1] = make_float2(v.y, 0.f);
-        } else {
-            dc[id.batch] = v;
-        }
-    }
-};
+// (WinAudioDecim, the weight of the decimation between two transforms, lives in fft_decim_rt.h: two translation units use it)
 
 // Stores bins k <= lo and k >= hi only.
 struct StorePruned {
@@ -755,7 +731,8 @@ bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int 
     if (ef.npass() != 2 || ea.npass() != 2) return false;
     const int64_t B = ef.desc().n, A = ea.desc().n;
     if (A >= B || (A & 1) || ea.desc().pass[1].L != ef.desc().pass[0].L) return false;
-    return fftk::fft_tile2_decim_applies(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()), count);
+    const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), B), d2 = ea.pass_dev(0, A, ea.tmp_stride());
+    return fftk::fft_tile2_decim_applies(d1, d2, count) || fftk::fft_tile2_decim_rt_applies(d1, d2, count);
 }
 
 void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2* tmp_f, float2* out, float2* tmp_a,
@@ -765,9 +742,12 @@ void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2
     fftk::LoadPlainT<false> ld{tmp_f};
     WinAudioDecim win{wr, dc, scale, (int)A, ef.desc().pass[0].L, 0};
     fftk::StorePlainT<false> st{tmp_a, 1.0f};
-    RC_REQUIRE(fftk::launch_fft_tile2_decim(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()),
-                                            count, ld, win, st, s),
-               RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
+    {   // the instantiated (L, L2) pairs first, then the kernel that takes L2 at run time
+        const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), B), d2 = ea.pass_dev(0, A, ea.tmp_stride());
+        RC_REQUIRE(fftk::launch_fft_tile2_decim(d1, d2, count, ld, win, st, s) ||
+                       launch_fft_tile2_decim_rt(d1, d2, count, tmp_f, win, tmp_a, s),
+                   RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
+    }
     fftk::LoadPlainT<false> ldl{tmp_a};
     fftk::StorePlainT<true> stl{out, 1.0f};
     FftPassDev last = ea.pass_dev(1, ea.tmp_stride(), A);
@@ -815,9 +795,12 @@ void fused_fft_decim_ifft_pairs(const FftEngine& ef, const FftEngine& ea, const 
     fftk::LoadPlainT<false> ld{tmp_f};
     WinAudioDecim win{wr, dc, scale, (int)A, ef.desc().pass[0].L, count};
     fftk::StorePlainT<false> st{tmp_a, 1.0f};
-    RC_REQUIRE(fftk::launch_fft_tile2_decim(ef.pass_dev(1, ef.tmp_stride(), B), ea.pass_dev(0, A, ea.tmp_stride()),
-                                            pairs, ld, win, st, s),
-               RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
+    {
+        const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), B), d2 = ea.pass_dev(0, A, ea.tmp_stride());
+        RC_REQUIRE(fftk::launch_fft_tile2_decim(d1, d2, pairs, ld, win, st, s) ||
+                       launch_fft_tile2_decim_rt(d1, d2, pairs, tmp_f, win, tmp_a, s),
+                   RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
+    }
     fftk::LoadPlainT<false> ldl{tmp_a};
     StoreRealImagSplit stl{y, (int)A, count};
     fftk::launch_fft_pass<kRowsOnly>(ea.pass_dev(1, ea.tmp_stride(), A), pairs, ldl, stl, s);

@@ -414,3 +414,66 @@ def test_run_each_on_a_mixed_band(rc, oracle):
             want = np.asarray(c.demodulator.run(ref.run_pruned(c.index)))
             assert got[c.index].shape == want.shape, (c.index, got[c.index].shape, want.shape)
             assert rel_err(got[c.index], want) <= TOL, (buf, c.index, plan[c.index])
+
+
+# ---- geometries other than BASELINE's: the fused chain is not benchmark-shaped ---------------------------------
+
+def _stages_run(lib, hip):
+    """{stage name: launches} from librcfm's stage profile (rcfm_profile_*)."""
+    out = {}
+    for st in range(lib.rcfm_profile_stage_count()):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        hip.check(lib.rcfm_profile_read(st, ctypes.byref(ms), ctypes.byref(cnt)))
+        out[lib.rcfm_profile_stage_name(st).decode()] = int(cnt.value)
+    return out
+
+
+@pytest.mark.parametrize("kind,B,A", [
+    ("WBFM", 256000, 32000),   # the reference's own benchmark shape (tests/benchmark.py:85): 500 x 512, L2 = 64
+    ("WBFM", 250000, 50000),   # 500 x 500, L2 = 100
+    ("WBFM", 200000, 40000),   # 400 x 500, L2 = 100
+    ("WBFM", 200000, 50000),   # 500 x 400, L2 = 100 (the planner's order 400 x 500 would need L2 = 125: swapped)
+    ("WBFM", 240000, 24000),   # 480 x 500, L2 = 50
+    ("WBFM", 192000, 48000),   # 480 x 400, L2 = 100
+    ("MFM", 256000, 32000),
+    ("FM", 200000, 40000),
+    ("MFM", 25000, 8000),      # 25 kHz narrow-band channels: 100 x 250, L2 = 80
+    ("FM", 20000, 8000),       # 100 x 200, L2 = 80
+])
+def test_fused_chain_on_other_geometries(rc, oracle, kind, B, A):
+    """wbfm.py:32-59 / mfm.py:24-40 accept any sizes.  For every two-pass B whose first-pass length n_1 divides A
+    into an even L2 = A / n_1 the audio decimation runs between FFT_B's last pass and IFFT_A's first on one tile
+    (k_fft_tile2_decim for the instantiated pairs, k_fft_tile2_decim_rt for the others) and, for WBFM, the pilot
+    chain runs as two-transform tiles: the stage profile must show the fused launches (no separate `ifft_A` /
+    `audio_spectrum` stage for WBFM, no `audio_spectrum` for FM / MFM) and the audio must match the reference loop
+    (multi_fm_server.py:100-106), two buffers, odd channel count."""
+    from radiocore._internal import hip
+    lib = hip.lib()
+    C = 3
+    raster = int(B * 1.25)
+    N = 10 * raster
+    centres = workloads.channel_grid(C, raster)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    stereo = kind == "WBFM"
+    ch = 2 if stereo else 1
+    dev = None if B >= 100000 else 0.2 * B
+    hip.check(lib.rcfm_profile_enable((1 << lib.rcfm_profile_stage_count()) - 1))
+    hip.check(lib.rcfm_profile_reset())
+    try:
+        for buf in range(2):
+            x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.4, stereo=stereo, deviation=dev)
+            x = np.roll(x, 911 * buf)
+            tuner.load(x)
+            ref.load(x)
+            audio = tuner.run_all()
+            assert audio.shape == (C, A, ch)
+            for c in ref.channels():
+                want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, ch)
+                assert rel_err(audio[c.index], want) <= TOL, (kind, B, A, buf, c.index, rel_err(audio[c.index], want))
+        ran = _stages_run(lib, hip)
+    finally:
+        hip.check(lib.rcfm_profile_enable(0))
+    print(kind, B, A, {k: v for k, v in ran.items() if v})
+    assert ran["audio_spectrum"] == 0, ran            # the decimation never ran as a kernel of its own
+    if kind == "WBFM":
+        assert ran["ifft_A"] == 0 and ran["fft_B"] > 0 and ran["hilbert_mask"] == 0 and ran["stereo_mix"] == 0, ran
