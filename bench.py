@@ -44,6 +44,10 @@ CONFIGS = {
     "cfg3": (10_000_000, 64, 240_000, 48_000, 150_000, "MFM"),
     "cfg5": (100_000_000, 8192, 12_500, 8_000, 12_000, "FM"),
     "small": (2_400_000, 16, 240_000, 48_000, 140_000, "WBFM"),
+    # geometries off the benchmark shape (reported under other_configs): the reference's own harness shape
+    # (tests/benchmark.py:85, WBFM(256e3, 32e3)) and a 200 kHz-channel band, batched like cfg4
+    "geo256k": (240_000_000, 1024, 256_000, 32_000, 220_000, "WBFM"),
+    "geo200k": (240_000_000, 1024, 200_000, 40_000, 200_000, "WBFM"),
 }
 
 # Algorithmic bytes of each stage per unit:
@@ -237,6 +241,30 @@ def measure_surface(name, x, centres, steps, warmup, abi_seconds):
     return out
 
 
+def stage_roofline(lib, step, N, B, A, kind, channels):
+    """`roofline` block of one configuration: one step with every stage bracketed by HIP events (on the stream the
+    kernels run on) finds the dominant stage; achieved = its algorithmic bytes per launch / its mean launch time."""
+    lib.rcfm_profile_reset()
+    lib.rcfm_profile_enable(ctypes.c_uint64((1 << lib.rcfm_profile_stage_count()) - 1))
+    reps = 3
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    prof = read_profile(lib)
+    lib.rcfm_profile_enable(ctypes.c_uint64(0))
+    dominant = max(prof, key=lambda k: prof[k][1])
+    _, ms, cnt = prof[dominant]
+    per_launch_s = ms * 1e-3 / max(cnt, 1)
+    launches_per_step = cnt / reps
+    units = 1.0 if dominant == "tuner_fft_N" else channels / max(launches_per_step, 1)
+    alg = stage_bytes(dominant, N, B, A, kind) * units
+    total = sum(v[1] for v in prof.values())
+    return {"bound": "hbm", "kernel": dominant, "achieved": round(alg / per_launch_s / 1e9, 1) if per_launch_s else 0.0,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(alg / per_launch_s / HBM_PEAK, 4) if per_launch_s else 0.0,
+            "traffic": None, "launch_us": round(per_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
+            "algorithmic_bytes_per_launch": alg, "share_of_step": round(ms / total, 3) if total else 0.0}
+
+
 def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
     """One extra configuration on this GPU (cfg3 / cfg5; cfg4 is the headline): K timed steps of
     rcfm_tuner_load + rcfm_pipeline_run, input resident in HBM, same accounting as the headline."""
@@ -264,6 +292,7 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     finite = bool(torch.isfinite(audio).all())
+    roof = stage_roofline(lib, step, N, B, A, kind, C)
     hip.check(lib.rcfm_demod_destroy(demod))
     hip.check(lib.rcfm_tuner_destroy(tuner))
     del audio
@@ -278,7 +307,10 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
         "ms_per_step": round(dt * 1e3, 4), "value": round(N / dt / 1e6, 1), "unit": "Msamples/s", "steps": steps,
         "path_algorithmic_GB": round(alg / 1e9, 3), "path_hbm_frac": round(alg / dt / HBM_PEAK, 4),
         "path_hbm_frac_read": round(path_read_bytes(N, C, B, A, kind) / dt / HBM_PEAK, 4),
-        "output_finite": finite, "parity": "tests/test_hip_configs.py::test_%s_full_size_%s" % (name, kind.lower()),
+        "roofline": roof,
+        "output_finite": finite,
+        "parity": ("tests/test_hip_configs.py::test_%s_full_size_%s" % (name, kind.lower()) if name.startswith("cfg") else
+                   "tests/test_hip_configs.py::test_fused_chain_on_other_geometries[%s-%d-%d] (reduced band)" % (kind, B, A)),
     }
 
 
@@ -324,9 +356,11 @@ def measure_batched_cfg2(lib, hip, steps, warmup, T=1024):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    roof = stage_roofline(lib, step, 0, B, A, "WBFM", T)
     hip.check(lib.rcfm_demod_destroy(demod))
     alg = T * (48.0 * B + 40.0 * A)
     return {
+        "roofline": roof,
         "workload": "cfg2 batched: %d one-second 240 kSPS buffers as %d channels of one WBFM.run (no tuner)" % (T, T),
         "ms_per_step": round(dt * 1e3, 4), "value": round(T * B / dt / 1e6, 1), "unit": "Msamples/s", "steps": steps,
         "path_algorithmic_GB": round(alg / 1e9, 3), "path_hbm_frac": round(alg / dt / HBM_PEAK, 4),
@@ -721,6 +755,8 @@ def main():
             "cfg3": measure_config("cfg3", lib, hip, 50, 5),
             "cfg5": measure_config("cfg5", lib, hip, 20, 3),
             "cfg2_batched": measure_batched_cfg2(lib, hip, 10, 2),
+            "geo256k": measure_config("geo256k", lib, hip, 10, 2, with_surface=False),
+            "geo200k": measure_config("geo200k", lib, hip, 10, 2, with_surface=False),
             "cfg2_single": measure_cfg2_single(),
             "cfg1_cpu": measure_cfg1_cpu(),
         }

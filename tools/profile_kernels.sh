@@ -8,10 +8,15 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$out" -o run -- python "$root/bench.py" --steps 5 --warmup 2 --cpu-channels 0 "$@" > "$out/bench.log" 2>&1 || true
+# the traced process runs ONLY the headline path (--no-extras, no CPU baseline): 2 warm-up + 1 profile pass + 5 timed steps
+rocprofv3 --kernel-trace --stats -d "$out" -o run -- python "$root/bench.py" --steps 5 --warmup 2 --cpu-channels 0 --no-extras "$@" > "$out/bench.log" 2>&1 || true
 db=$(find "$out" -name '*.db' | head -1)
 if [ -n "$db" ]; then
-    python "$root/tools/rocpd_summary.py" "$db" 40 > "$root/gpurun_out/${tag}_kernel_stats.md"
+    python "$root/tools/rocpd_summary.py" "$db" --per-step 8 > "$root/gpurun_out/${tag}_kernel_stats.md"
+    echo >> "$root/gpurun_out/${tag}_kernel_stats.md"
+    echo "Every kernel of the traced process (input synthesis included):" >> "$root/gpurun_out/${tag}_kernel_stats.md"
+    echo >> "$root/gpurun_out/${tag}_kernel_stats.md"
+    python "$root/tools/rocpd_summary.py" "$db" 40 >> "$root/gpurun_out/${tag}_kernel_stats.md"
 else
     csv=$(find "$out" -name '*kernel_stats.csv' | head -1)
     cp "$csv" "$root/gpurun_out/${tag}_kernel_stats.csv"
