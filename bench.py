@@ -444,13 +444,48 @@ def main():
     # process group, asynchronous double-buffered gather into views of the result, barrier, max-over-ranks -- which a
     # one-GPU box can execute (a one-rank communicator is legal) although it cannot execute N > 1 itself.
     multi = world > 1 or os.environ.get("RCFM_BENCH_FORCE_DIST") == "1"
+    # N > 1 only: a rank that stops making progress (a peer died, a transfer never matched) must end the run with a
+    # message instead of holding the node until the lease expires.  `phase` says where it was.
+    phase = {"name": "init", "step": -1, "t": time.monotonic()}
+
+    def progress(name, step=-1):
+        phase.update(name=name, step=step, t=time.monotonic())
+
     if multi:
+        import datetime
+        import threading
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        if os.environ.get("RCFM_BENCH_FORCE_DIST") == "1":
+            os.environ.setdefault("RCFM_GATHER_FORCE_COLLECTIVE", "1")   # exercise the collective on a one-rank group
+        limit = float(os.environ.get("RCFM_BENCH_TIMEOUT", "300"))
+
+        def fail(what):
+            sys.stderr.write(json.dumps({"error": what, "rank": rank, "world": world, "phase": phase["name"],
+                                         "step": phase["step"], "parallelism": args.parallelism, "backend": backend}) + "\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        def watchdog():
+            while True:
+                time.sleep(1.0)
+                idle = time.monotonic() - phase["t"]
+                if phase["name"] == "done":
+                    return
+                if idle > limit:
+                    fail("bench.py made no progress for %.0f s" % idle)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        to = datetime.timedelta(seconds=limit)
+        progress("process group rendezvous")
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=to)
+            else:
+                dist.init_process_group(backend, timeout=to)
+        except Exception as e:                                   # a peer never arrived
+            fail("bench.py made no progress: process group rendezvous failed (%s: %s)" % (type(e).__name__, str(e)[:200]))
+        progress("process group up")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     from radiocore._internal import hip
@@ -532,8 +567,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for k in range(args.warmup):
+        progress("warm-up", k)
         step()
+    progress("warm-up barrier")
     barrier()
 
     # pass 1 (untimed): every stage bracketed, to find the dominant one
@@ -558,19 +595,43 @@ def main():
     # dominant stage keeps its event pairs (on the stream the kernels run on)
     lib.rcfm_profile_reset()
     lib.rcfm_profile_enable(ctypes.c_uint64(1 << prof_all[dominant][0]))
+    if ring is not None:
+        ring.enable_timing()
+    progress("barrier before the timed region")
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        progress("timed step", k)
         step()
+    progress("barrier after the timed region")
     barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     dom = read_profile(lib)[dominant]
     lib.rcfm_profile_enable(ctypes.c_uint64(0))
 
+    per_rank = None
     if multi:
+        progress("max over ranks")
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # where each rank's step went (HIP-event stage times of the untimed profile pass; the ring's own event pairs):
+        # the first thing to read when a multi-GPU number looks wrong
+        fft_pb = prof_all["tuner_fft_N"][1]                       # per buffer of this rank (rotating: one in `world`)
+        chan_pb = sum(v[1] for k, v in prof_all.items() if k != "tuner_fft_N")
+        mine_ms = 1e3 * own_elapsed / args.steps
+        row = {"rank": rank, "channels": mine, "step_ms": round(mine_ms, 4), "fft_ms": round(fft_pb, 4),
+               "chan_ms": round(chan_pb, 4), "send_ms": 0.0, "wait_ms": 0.0}
+        if ring is not None:
+            tsum = ring.timing_summary() or {}
+            row.update(fft_ms=tsum.get("fft_ms", 0.0), send_ms=tsum.get("send_ms", 0.0), wait_ms=tsum.get("wait_ms", 0.0),
+                       owned_buffers=tsum.get("fft_count", 0))
+        row["other_ms"] = round(mine_ms - row["chan_ms"] - row["wait_ms"] - (0.0 if rotating else row["fft_ms"]), 4)
+        progress("per-rank rows")
+        rows = [None] * world
+        dist.all_gather_object(rows, row)
+        per_rank = rows
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * args.steps / elapsed / 1e6
@@ -642,6 +703,11 @@ def main():
         # replicated FFT: Amdahl; rotating owner: every stage divides by the world size
         result["amdahl_bound_speedup"] = float(world) if rotating else round(
             alg_all / (alg_fft + (alg_all - alg_fft) / world), 3)
+        # per rank: step_ms = its own K steps / K; fft_ms = one wideband FFT (replicated: every buffer; rotating: on the
+        # owner's stream, once per `world` buffers); chan_ms = its channels' stages per buffer; send_ms = the owner's
+        # sends of one buffer (rotating); wait_ms = how long the channel stream waited for a buffer's bins (rotating);
+        # other_ms = what is left of the step (gather exposure, launch gaps)
+        result["per_rank"] = per_rank
         if rotating:
             result["rotating_owner"] = {
                 "lookahead": ring.lookahead, "spectrum_slots": len(ring.slots),
@@ -650,6 +716,7 @@ def main():
                 "ffts_per_rank_per_buffer": round(1.0 / world, 4)}
 
         # the last gathered block (outside the timed region): every rank's rows arrived
+        progress("gather check")
         step()
         barrier()
         if rank == 0:
@@ -765,6 +832,7 @@ def main():
                              "cfg3": result["other_configs"]["cfg3"].pop("surface")}
     if rank == 0:
         print(json.dumps(result))
+    progress("done")
     if multi:
         dist.destroy_process_group()
 

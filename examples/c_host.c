@@ -122,6 +122,69 @@ int main(int argc, char** argv) {
         if (fwrite(audio_host, sizeof(float), (size_t)C * A * 2, f) != (size_t)C * A * 2) return 4;
     }
     fclose(f);
+
+    /* ---- the same buffers through the ROTATING FFT OWNER's protocol on a one-rank communicator ---------------------
+     * (rcfm.h, "the rotating FFT owner's hand-over"): the owner transforms buffer b into slot `own`, hands the bins this
+     * rank's channels read to the reader's slot `mine` point to point (here: to itself, a device copy inside one
+     * ncclGroup), the reader adopts them and runs its channels.  With G GPUs the only differences are peer != 0 and
+     * that owner and reader are different processes.  A fresh demodulator (fresh de-emphasis state) must reproduce the
+     * audio file written above, bit for bit: the spectrum the channels read is the same. */
+    {
+        int64_t halo = 0, nn = 0, first_bin = 0, nbins = 0;
+        rcfm_demod_t demod2;
+        void *own = NULL, *mine = NULL, *xdev = NULL;
+        CHECK(rcfm_demod_create(RCFM_WBFM, C, B, A, 75e-6, 0, &demod2));
+        CHECK(rcfm_tuner_spectrum_layout(tuner, &halo, &nn));
+        CHECK(rcfm_malloc(&own, sizeof(float) * 2 * (size_t)(nn + 2 * halo)));
+        CHECK(rcfm_malloc(&mine, sizeof(float) * 2 * (size_t)(nn + 2 * halo)));
+        CHECK(rcfm_malloc(&xdev, sizeof(float) * 2 * N));
+        CHECK(rcfm_tuner_window(tuner, 0, C, &first_bin, &nbins));
+        /* a circular window as at most two pieces [a, b) of [0, n) */
+        int64_t seg[2][2] = {{first_bin, first_bin + nbins}, {0, 0}};
+        if (nbins >= nn) {
+            seg[0][0] = 0;
+            seg[0][1] = nn;
+        } else if (first_bin + nbins > nn) {
+            seg[0][1] = nn;
+            seg[1][1] = first_bin + nbins - nn;
+        }
+        snprintf(path, sizeof(path), "%s/c_host_audio.bin", dir);
+        f = fopen(path, "rb");
+        float* want = (float*)malloc(sizeof(float) * C * A * 2);
+        if (!f || !want) return 4;
+        for (int b = 0; b < BUFFERS; ++b) {
+            CHECK(rcfm_memcpy_h2d(xdev, ring + (size_t)b * 2 * N, sizeof(float) * 2 * N, NULL));
+            CHECK(rcfm_tuner_attach_spectrum(tuner, own, 0, 0));       /* owner: FFT into its slot */
+            CHECK(rcfm_tuner_load(tuner, xdev, NULL));
+            CHECK(rcfm_comm_group_start(comm));                         /* hand-over: owner -> reader (rank 0 -> rank 0) */
+            for (int k = 0; k < 2; ++k) {
+                const size_t n = (size_t)(seg[k][1] - seg[k][0]);
+                const size_t at = sizeof(float) * 2 * (size_t)(halo + seg[k][0]);
+                CHECK(rcfm_send_bins(comm, 0, (const char*)own + at, n, NULL));
+                CHECK(rcfm_recv_bins(comm, 0, (char*)mine + at, n, NULL));
+            }
+            CHECK(rcfm_comm_group_end(comm));
+            CHECK(rcfm_tuner_attach_spectrum(tuner, mine, 0, 0));      /* reader: adopt the bins, run its channels */
+            CHECK(rcfm_tuner_adopt(tuner, 0, C, NULL));
+            CHECK(rcfm_pipeline_run(tuner, demod2, 0, C, block, NULL));
+            CHECK(rcfm_memcpy_d2h(audio_host, block, sizeof(float) * C * A * 2, NULL));
+            CHECK(rcfm_stream_sync(NULL));
+            if (fread(want, sizeof(float), (size_t)C * A * 2, f) != (size_t)C * A * 2) return 4;
+            if (memcmp(want, audio_host, sizeof(float) * C * A * 2) != 0) {
+                fprintf(stderr, "rotating owner: buffer %d differs from the direct path\n", b);
+                return 6;
+            }
+            printf("rotating owner, buffer %d: window of %lld of %lld bins handed over, audio identical\n", b,
+                   (long long)(nbins < nn ? nbins : nn), (long long)nn);
+        }
+        fclose(f);
+        free(want);
+        CHECK(rcfm_tuner_attach_spectrum(tuner, NULL, 0, 0));
+        CHECK(rcfm_demod_destroy(demod2));
+        CHECK(rcfm_free(own));
+        CHECK(rcfm_free(mine));
+        CHECK(rcfm_free(xdev));
+    }
     CHECK(rcfm_host_unregister(ring));
     CHECK(rcfm_comm_destroy(comm));
     CHECK(rcfm_feeder_destroy(feeder));

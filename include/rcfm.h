@@ -200,6 +200,21 @@ int rcfm_feeder_destroy(rcfm_feeder_t f);
 int rcfm_comm_unique_id(void* id128_host);
 int rcfm_comm_init_rank(int world, int rank, const void* id128_host, rcfm_comm_t* out);
 int rcfm_gather_audio(rcfm_comm_t c, int root, const void* send, size_t floats_per_rank, void* recv, void* stream);
+/* The rotating FFT owner's hand-over without torch.distributed (Python: radiocore.tools.sharding.SpectrumRing; no
+ * reference counterpart -- its one process keeps Tuner._buffer, tuner.py:57,138, to itself).  Rank i mod G runs the
+ * wideband FFT of buffer i into a spectrum slot (rcfm_tuner_attach_spectrum + rcfm_tuner_load) and sends every peer the
+ * bins that peer's channels read (rcfm_tuner_window: at most two contiguous pieces of the circular spectrum); the peer
+ * receives them into the same positions of its own slot and calls rcfm_tuner_adopt.  Point-to-point over xGMI:
+ *   group_start / group_end   bracket all sends and receives of one buffer (ncclGroupStart / ncclGroupEnd): they are
+ *                             posted together, so no ordering between peers can deadlock
+ *   send_bins(c, peer, p, n)  n complex64 bins from device pointer p to rank `peer`, asynchronously on `stream`
+ *   recv_bins(c, peer, p, n)  the matching receive.  peer = this rank is allowed inside a group (send + receive to
+ *                             itself: a device copy) -- a one-GPU host can run the whole protocol.
+ * examples/c_host.c runs it on a one-rank communicator. */
+int rcfm_comm_group_start(rcfm_comm_t c);
+int rcfm_send_bins(rcfm_comm_t c, int peer, const void* bins, size_t nbins, void* stream);
+int rcfm_recv_bins(rcfm_comm_t c, int peer, void* bins, size_t nbins, void* stream);
+int rcfm_comm_group_end(rcfm_comm_t c);
 int rcfm_comm_destroy(rcfm_comm_t c);
 
 /* ---- primitives (class parity with radiocore/analog) ---------------------- */

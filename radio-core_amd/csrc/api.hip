@@ -273,6 +273,8 @@ struct rcfm_tuner_s {
     float2* ext = nullptr;   // rcfm_tuner_attach_spectrum: caller-owned storage of the same layout instead of X
     float2* spectrum() { return (ext ? ext : X.as<float2>()) + halo; }
     DeviceBuffer work;
+    DeviceBuffer forward_work;                 // rocFFT fallback of the FORWARD transform: its own workspace -- load() may run on
+                                               // another stream than run() (sharding.SpectrumRing), and reserve() may reallocate
     std::unique_ptr<FftPlan> forward;          // rocFFT fallback for lengths outside the engine
     std::unique_ptr<FftEngine> forward_engine;
     DeviceBuffer forward_tmp;                  // engine: the last pass cannot run in place
@@ -330,6 +332,11 @@ struct rcfm_tuner_s {
     // The same window in bins: [first_bin, first_bin + nbins) modulo n (nbins = n: everything).
     void bin_window(int first, int count, int64_t* first_bin, int64_t* nbins) const {
         FftRowWindow w{0, 0};
+        if (count == 0) {            // a rank that owns no channels (C < G) reads nothing
+            *first_bin = 0;
+            *nbins = 0;
+            return;
+        }
         if (!row_window(first, count, &w)) {
             *first_bin = 0;
             *nbins = n;
@@ -877,6 +884,10 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -901,8 +912,14 @@ Rccl& rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.Gather = reinterpret_cast<decltype(r.Gather)>(dlsym(r.lib, "ncclGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
     });
-    RC_REQUIRE(r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Gather, RCFM_ERR_RUNTIME,
+    RC_REQUIRE(r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Gather && r.Send && r.Recv && r.GroupStart &&
+                   r.GroupEnd,
+               RCFM_ERR_RUNTIME,
                "RCCL (librccl.so) is not available in this process");
     return r;
 }
@@ -918,6 +935,7 @@ Rccl& rccl() {
 struct rcfm_comm_s {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
+    int group_depth = 0;   // rcfm_comm_group_start without its rcfm_comm_group_end
 };
 
 // Overlapped host -> device ingest (rcfm_feeder_*): `depth` device slots, one copy stream, an event pair per slot.
@@ -1025,7 +1043,7 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
             t->forward_tmp.reset(sizeof(float2) * (size_t)t->forward_engine->tmp_stride());
         } else {
             t->forward = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, 1, false);
-            t->work.reserve(t->forward->work_bytes());
+            t->forward_work.reserve(t->forward->work_bytes());
         }
         *out = t.release();
     });
@@ -1046,8 +1064,8 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
                 t->forward_engine->c2c(static_cast<const float2*>(x), t->spectrum(), t->forward_tmp.as<float2>(),
                                        1, false, 1.0f, as_stream(stream), &w);
             } else {
-                t->work.reserve(t->forward->work_bytes());
-                t->forward->exec(const_cast<void*>(x), t->spectrum(), t->work.get(), as_stream(stream));
+                t->forward_work.reserve(t->forward->work_bytes());
+                t->forward->exec(const_cast<void*>(x), t->spectrum(), t->forward_work.get(), as_stream(stream));
             }
             if (t->halo && !halo_done) {
                 float2* X = t->spectrum();
@@ -1459,6 +1477,47 @@ int rcfm_gather_audio(rcfm_comm_t c, int root, const void* send, size_t floats_p
         RC_REQUIRE(root >= 0 && root < c->world, RCFM_ERR_INDEX, "root rank outside the communicator");
         RC_REQUIRE(c->rank != root || recv != nullptr, RCFM_ERR_ARG, "the root rank needs a receive buffer");
         RC_NCCL(rccl().Gather(send, recv, floats_per_rank, ncclFloat32, root, c->comm, as_stream(stream)));
+    });
+}
+
+// ---- multi-GPU: the spectrum hand-over of the rotating FFT owner -------------------------
+
+int rcfm_comm_group_start(rcfm_comm_t c) {
+    return guarded([&] {
+        RC_REQUIRE(c, RCFM_ERR_ARG, "NULL communicator");
+        RC_NCCL(rccl().GroupStart());
+        ++c->group_depth;
+    });
+}
+
+int rcfm_comm_group_end(rcfm_comm_t c) {
+    return guarded([&] {
+        RC_REQUIRE(c, RCFM_ERR_ARG, "NULL communicator");
+        RC_REQUIRE(c->group_depth > 0, RCFM_ERR_STATE, "rcfm_comm_group_end without rcfm_comm_group_start");
+        --c->group_depth;
+        RC_NCCL(rccl().GroupEnd());
+    });
+}
+
+int rcfm_send_bins(rcfm_comm_t c, int peer, const void* bins, size_t nbins, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(c && (bins || nbins == 0), RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(peer >= 0 && peer < c->world, RCFM_ERR_INDEX, "peer rank outside the communicator");
+        RC_REQUIRE(peer != c->rank || c->group_depth > 0, RCFM_ERR_STATE,
+                   "a transfer to this rank itself needs its receive in the same group (rcfm_comm_group_start)");
+        if (nbins == 0) return;   // a rank that owns no channels reads no bins
+        RC_NCCL(rccl().Send(bins, 2 * nbins, ncclFloat32, peer, c->comm, as_stream(stream)));
+    });
+}
+
+int rcfm_recv_bins(rcfm_comm_t c, int peer, void* bins, size_t nbins, void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(c && (bins || nbins == 0), RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(peer >= 0 && peer < c->world, RCFM_ERR_INDEX, "peer rank outside the communicator");
+        RC_REQUIRE(peer != c->rank || c->group_depth > 0, RCFM_ERR_STATE,
+                   "a transfer from this rank itself needs its send in the same group (rcfm_comm_group_start)");
+        if (nbins == 0) return;
+        RC_NCCL(rccl().Recv(bins, 2 * nbins, ncclFloat32, peer, c->comm, as_stream(stream)));
     });
 }
 

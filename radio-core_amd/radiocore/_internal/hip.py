@@ -71,6 +71,10 @@ SIGNATURES = {
     "rcfm_comm_unique_id": [_vp],
     "rcfm_comm_init_rank": [_i, _i, _vp, ctypes.POINTER(_vp)],
     "rcfm_gather_audio": [_vp, _i, _vp, _sz, _vp, _vp],
+    "rcfm_comm_group_start": [_vp],
+    "rcfm_send_bins": [_vp, _i, _vp, _sz, _vp],
+    "rcfm_recv_bins": [_vp, _i, _vp, _sz, _vp],
+    "rcfm_comm_group_end": [_vp],
     "rcfm_comm_destroy": [_vp],
     "rcfm_resampler_create": [_i, _i, _i, _i, ctypes.POINTER(_vp)],
     "rcfm_resampler_run": [_vp, _vp, _vp, _vp],

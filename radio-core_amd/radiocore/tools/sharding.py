@@ -10,6 +10,8 @@ The reference has no multi-device code at all; its per-channel loop is
 examples/multi_fm_server.py:100-106.
 """
 
+import time
+
 __all__ = ["channel_range", "channel_counts", "gather_audio", "GatherHandle", "SpectrumRing", "window_segments"]
 
 
@@ -52,11 +54,18 @@ def gather_audio(local, channels, dst=0, group=None, out=None, async_op=False):
     the work already queued on the caller's stream, so buffer i can travel over xGMI while the
     kernels of buffer i+1 run (`local` and `out` must stay untouched until wait()).
     """
+    import os
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized():
+    # One rank: nothing travels -- `local` IS the result, whatever it is (a numpy block from run_all() included).
+    # RCFM_GATHER_FORCE_COLLECTIVE=1 (bench.py's RCFM_BENCH_FORCE_DIST runs, tests/test_nccl_world1.py) runs the
+    # collective on a one-rank group anyway: that is how a one-GPU box exercises the RCCL path.
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and
+                                     os.environ.get("RCFM_GATHER_FORCE_COLLECTIVE") != "1"):
+        if out is not None and out is not local:
+            out.copy_(local if isinstance(local, torch.Tensor) else torch.as_tensor(local))
+            local = out
         return GatherHandle(None, lambda: local) if async_op else local
-    # (a one-rank group runs the collective like any other: that is how a one-GPU box exercises the RCCL path)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = channel_counts(world, channels)
@@ -136,7 +145,8 @@ class SpectrumRing:
         self.ranges = [channel_range(r, self.world, self.channels) for r in range(self.world)]
         lo, hi = self.ranges[self.rank]
         tuner.shard(lo, hi - lo)
-        self.segments = [window_segments(*tuner.window(self.n, a, b - a), self.n) for a, b in self.ranges]
+        self.segments = [window_segments(*tuner.window(self.n, a, b - a), self.n) if b > a else []
+                         for a, b in self.ranges]
         self.slots = [tuner.spectrum_slot(self.n) for _ in range(self.lookahead + 1)]
         self.halo = int(getattr(self.slots[0], "rcfm_halo", (self.slots[0].shape[0] - self.n) // 2))
         self._pending = {}      # buffer index -> (own, outstanding works, event of the owner's FFT)
@@ -146,6 +156,7 @@ class SpectrumRing:
         # kernels (and a host-fed buffer's PCIe copy does not stall them); `staging` receives host-fed buffers.
         self._side = None
         self._staging = None
+        self._timing = None     # enable_timing(): event pairs / wall-clock samples of the FFT, the sends and the waits
         if self.slots[0].is_cuda:
             import torch
             self._torch = torch
@@ -155,7 +166,8 @@ class SpectrumRing:
         return i % self.world
 
     def _views(self, slot, rank):
-        return [slot[self.halo + a:self.halo + b] for a, b in self.segments[rank]]
+        # (a rank without channels -- C < G -- reads nothing: no pieces, no transfer)
+        return [slot[self.halo + a:self.halo + b] for a, b in self.segments[rank] if b > a]
 
     def bytes_sent_per_buffer(self):
         """What the owner of a buffer puts on the links (all peers together)."""
@@ -186,15 +198,27 @@ class SpectrumRing:
                         dev = self._staging[(i // self.world) % 2]
                         dev.copy_(x, non_blocking=True)
                         x = dev
+                    e0 = self._mark(self._side)
                     self.tuner.attach(slot, self.n, None)
                     self.tuner.load(x, whole=True)
+                    e1 = self._mark(self._side)
                     works = self._send(slot)
                     event = torch.cuda.Event()
                     event.record(self._side)
+                    if self._timing is not None:
+                        for w in works:
+                            w.wait()              # (the side stream waits; the host does not) -> e2 = the sends have left
+                        self._timing["fft"].append((e0, e1))
+                        self._timing["send"].append((e1, self._mark(self._side)))
             else:
+                t0 = time.perf_counter()
                 self.tuner.attach(slot, self.n, None)
                 self.tuner.load(x, whole=True)
+                t1 = time.perf_counter()
                 works = self._send(slot)
+                if self._timing is not None:
+                    self._timing["fft"].append(1e3 * (t1 - t0))
+                    self._timing["send"].append(1e3 * (time.perf_counter() - t1))
         elif self.world > 1:
             src = self.owner(i)
             views = self._views(slot, self.rank)
@@ -231,10 +255,14 @@ class SpectrumRing:
             raise RuntimeError("SpectrumRing.acquire: buffers are acquired in order, after their submit")
         self._next_acquire += 1
         own, works, event = self._pending.pop(i)
+        t0 = time.perf_counter()
+        ea = self._mark(None)
         if event is not None:
             self._torch.cuda.current_stream().wait_event(event)      # this buffer's FFT (side stream) only
         for w in works:
             w.wait()                  # RCCL: orders the current stream behind the transfer
+        if self._timing is not None:
+            self._timing["wait"].append((ea, self._mark(None)) if ea is not None else 1e3 * (time.perf_counter() - t0))
         slot = self.slots[i % len(self.slots)]
         lo, hi = self.ranges[self.rank]
         if own:
@@ -242,6 +270,32 @@ class SpectrumRing:
         else:
             self.tuner.attach(slot, self.n, None)
             self.tuner.adopt(self.n, lo, hi - lo)
+
+    # ---- where a rank's time goes (bench.py prints it per rank for N > 1) ----------------------------------------
+
+    def enable_timing(self):
+        """From now on: time of every owned buffer's FFT and sends (on the owner's stream) and how long the channel
+        stream had to wait for a buffer's bins in acquire().  timing_summary() returns the means in milliseconds."""
+        self._timing = {"fft": [], "send": [], "wait": []}
+
+    def _mark(self, stream):
+        if self._timing is None or self._side is None:
+            return None
+        e = self._torch.cuda.Event(enable_timing=True)
+        e.record(stream if stream is not None else self._torch.cuda.current_stream())
+        return e
+
+    def timing_summary(self):
+        if self._timing is None:
+            return None
+        if self._side is not None:
+            self._torch.cuda.synchronize()
+        out = {}
+        for key, samples in self._timing.items():
+            ms = [s[0].elapsed_time(s[1]) if isinstance(s, tuple) else s for s in samples]
+            out[key + "_ms"] = round(sum(ms) / len(ms), 4) if ms else 0.0
+            out[key + "_count"] = len(ms)
+        return out
 
     def drain(self):
         """Complete every transfer that has been posted (acquire whatever is still in flight, without running it)."""

@@ -106,8 +106,12 @@ class Tuner(Injector):
 
     def _recalculate(self, added=None):
         # tuner.py:163-174.  The reference recomputes min / max / sum over every channel on each add_channel (O(C^2)
-        # to set up C channels: 2.9 s for 8192); the running forms below give the same floats -- min and max are
-        # exact, and Python's sum() adds left to right exactly like the running total -- in O(1) per channel.
+        # to set up C channels: 2.9 s for 8192); the running forms below give the same floats in O(1) per channel: min
+        # and max are exact, and the running total equals sum() whenever the bandwidths are integer-valued floats below
+        # 2^53 (every partial sum is exact) -- the only bandwidths with a meaning here, since int(bandwidth) is the
+        # channel's sample count (tuner.py:153).  For non-integer bandwidths Python >= 3.12's compensated sum() may
+        # differ from the running total in the last bit.  Channel objects are not expected to change after add_channel
+        # (the device handle is keyed by the list's version, not by its contents).
         self._version += 1
         if added is not None and self._lo is not None:
             self._lo = min(self._lo, added.lower_frequency)
@@ -166,9 +170,12 @@ class Tuner(Injector):
         h = self._device_tuner(n)
         if whole and self._shard is not None:
             hip.check(self._lib.rcfm_tuner_shard(h, 0, len(self._bounds)))
-        hip.check(self._lib.rcfm_tuner_load(h, hip.ptr(x), hip.stream()))
-        if whole and self._shard is not None:
-            hip.check(self._lib.rcfm_tuner_shard(h, self._shard[0], self._shard[1]))
+            try:
+                hip.check(self._lib.rcfm_tuner_load(h, hip.ptr(x), hip.stream()))
+            finally:      # a failed load must not leave the handle sharded to every channel
+                hip.check(self._lib.rcfm_tuner_shard(h, self._shard[0], self._shard[1]))
+        else:
+            hip.check(self._lib.rcfm_tuner_load(h, hip.ptr(x), hip.stream()))
         self._input = x            # keeps the buffer alive until the FFT has consumed it
         self._loaded_size = n
 
@@ -182,11 +189,20 @@ class Tuner(Injector):
         t.rcfm_halo = int(halo.value)
         return t
 
+    def _same_handle(self, n, what):
+        """The device handle for length n -- refusing to REBUILD it: a handle of another length would silently drop the
+        attached spectrum and the loaded state (the handle is keyed by (n, channel-list version))."""
+        if self._handle is not None and self._handle_key is not None and self._handle_key[0] != int(n) and \
+                self._handle_key[1] == self._version:
+            raise ValueError("%s: this tuner's device handle was built for %d-sample buffers, not %d"
+                             % (what, self._handle_key[0], int(n)))
+        return self._device_tuner(int(n))
+
     def attach(self, slot, n, loaded=None):
         """Use `slot` (from spectrum_slot) as the spectrum from now on; loaded = (first, count): it already holds the
         bins those channels read (None: nothing yet -- a load or adopt must follow)."""
         first, count = loaded if loaded is not None else (0, 0)
-        hip.check(self._lib.rcfm_tuner_attach_spectrum(self._device_tuner(int(n)), hip.ptr(slot), int(first), int(count)))
+        hip.check(self._lib.rcfm_tuner_attach_spectrum(self._same_handle(n, "attach"), hip.ptr(slot), int(first), int(count)))
         self._slot = slot          # keeps the storage alive while the handle points at it
         self._loaded_size = int(n) if loaded is not None else None
 
@@ -199,7 +215,7 @@ class Tuner(Injector):
 
     def adopt(self, n, first, count):
         """The caller has written window(n, first, count) into the attached slot: accept it as loaded."""
-        hip.check(self._lib.rcfm_tuner_adopt(self._device_tuner(int(n)), int(first), int(count), hip.stream()))
+        hip.check(self._lib.rcfm_tuner_adopt(self._same_handle(n, "adopt"), int(first), int(count), hip.stream()))
         self._loaded_size = int(n)
 
     def _ready(self):

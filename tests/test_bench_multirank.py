@@ -54,3 +54,29 @@ def test_two_rank_dry_run_prints_one_contract_line(parallelism):
         assert 1.0 < r["amdahl_bound_speedup"] < 2.0
     g = r["gather_check"]
     assert g["finite"] and g["own_block_equal"] and g["blocks_with_audio"] == g["blocks"] == 2
+    # where each rank's time went: one row per rank, the keys a first multi-GPU run is debugged with
+    rows = r["per_rank"]
+    assert [row["rank"] for row in rows] == [0, 1]
+    for row in rows:
+        assert {"step_ms", "fft_ms", "send_ms", "wait_ms", "chan_ms", "other_ms", "channels"} <= set(row)
+        assert row["step_ms"] > 0 and row["fft_ms"] > 0 and row["chan_ms"] > 0 and row["channels"] == r["config"]["channels_per_gpu"]
+        if parallelism == "rotating":
+            assert row["owned_buffers"] >= 1 and row["send_ms"] >= 0 and row["wait_ms"] >= 0
+
+
+@pytest.mark.timeout(300)
+def test_a_stalled_rank_fails_loudly_instead_of_hanging():
+    """RCFM_BENCH_TIMEOUT: rank 1 is started without its peer ever joining the rendezvous of the process group's first
+    collective... simulated here by a one-rank launch that claims a world of 2 it cannot reach: the process must end
+    within the limit with a JSON error line on stderr naming rank and phase, not hang."""
+    env = dict(os.environ, RCFM_BENCH_DEVICE="0", RCFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RCFM_BENCH_TIMEOUT="8", RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "small"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]        # no contract line from a failed run
+    err = [ln for ln in out.stderr.splitlines() if ln.startswith("{")]
+    assert err, out.stderr[-2000:]
+    msg = json.loads(err[-1])
+    assert msg["rank"] == 0 and msg["world"] == 2 and "no progress" in msg["error"] and msg["phase"]

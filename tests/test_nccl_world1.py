@@ -35,6 +35,7 @@ def _worker(rank, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["RCFM_GATHER_FORCE_COLLECTIVE"] = "1"      # a one-rank group would otherwise return `local` untouched
     for p in (ROOT, os.path.join(ROOT, "radio-core_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -102,3 +103,50 @@ def test_bench_one_rank_through_the_rccl_code_path(parallelism):
     g = r["gather_check"]
     assert g["finite"] and g["own_block_equal"] and g["blocks_with_audio"] == g["blocks"] == 1
     assert r["channel_stage_value"]["value"] > 0
+
+
+def _bins_worker(rank, out_path):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for p in (ROOT, os.path.join(ROOT, "radio-core_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import ctypes
+    import torch
+    torch.cuda.set_device(0)
+    from radiocore._internal import hip
+    lib = hip.lib()
+    token = (ctypes.c_ubyte * 128)()
+    hip.check(lib.rcfm_comm_unique_id(token))
+    comm = ctypes.c_void_p()
+    hip.check(lib.rcfm_comm_init_rank(1, 0, token, ctypes.byref(comm)))
+    n = 1 << 20
+    a = torch.view_as_complex(torch.randn(n, 2, device="cuda"))
+    b = torch.zeros_like(a)
+    segs = [(4096, 300000), (700001, n)]                   # two pieces, as a wrapping window has
+    hip.check(lib.rcfm_comm_group_start(comm))
+    for lo, hi in segs:
+        hip.check(lib.rcfm_send_bins(comm, 0, hip.ptr(a[lo:hi]), hi - lo, hip.stream()))
+        hip.check(lib.rcfm_recv_bins(comm, 0, hip.ptr(b[lo:hi]), hi - lo, hip.stream()))
+    hip.check(lib.rcfm_send_bins(comm, 0, None, 0, hip.stream()))    # a rank without channels: nothing to move
+    hip.check(lib.rcfm_comm_group_end(comm))
+    torch.cuda.synchronize()
+    ok = all(torch.equal(a[lo:hi], b[lo:hi]) for lo, hi in segs)
+    ok = ok and float(b[:4096].abs().max()) == 0.0 and float(b[300000:700001].abs().max()) == 0.0
+    codes = [lib.rcfm_send_bins(comm, 0, hip.ptr(a), 16, hip.stream()),       # to itself outside a group: refused
+             lib.rcfm_recv_bins(comm, 1, hip.ptr(b), 16, hip.stream()),       # no such rank
+             lib.rcfm_comm_group_end(comm)]                                   # no group open
+    hip.check(lib.rcfm_comm_destroy(comm))
+    np.save(out_path, np.array([int(ok)] + codes))
+
+
+@pytest.mark.timeout(600)
+def test_send_recv_bins_on_a_one_rank_communicator(tmp_path):
+    """rcfm_comm_group_start / rcfm_send_bins / rcfm_recv_bins / rcfm_comm_group_end (the rotating owner's hand-over for
+    hosts without torch.distributed): a rank sending to itself inside one group is a device copy -- the whole protocol
+    runs on a one-GPU box (examples/c_host.c does the same from C)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "bins.npy")
+    mp.spawn(_bins_worker, args=(out,), nprocs=1, join=True)
+    ok, send_self, recv_bad_peer, end_without_start = np.load(out)
+    assert ok == 1
+    assert send_self == -5 and recv_bad_peer == -2 and end_without_start == -5     # RCFM_ERR_STATE, _INDEX, _STATE
