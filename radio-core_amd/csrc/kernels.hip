@@ -389,7 +389,23 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
         dst[0] = make_float4(src[0].x, src[0].y, src[1].x, src[1].y);
         dst[1] = make_float4(src[2].x, src[2].y, src[3].x, src[3].y);
     }
-    if (t0 - H >= 0 && t0 + T - 1 + H <= last) {   // workgroup-uniform: no reflection anywhere in the tile
+    // Edge tiles (scipy filtfilt, padtype="odd", bandpass.py:72): the odd reflection of m about the first / last sample is
+    // written INTO the LDS window -- m[q] = 2 m[0] - m[-q] for q < 0, 2 m[last] - m[2 last - q] for last < q <= last + H --
+    // and the tile then runs the same packed FIR as every other tile.  (Until round 4 the two edge tiles of a channel
+    // took a scalar loop with run-time tap indexing: 55 us, invisible under 1024 channels, 40 % of a single WBFM.run.)
+    const bool inner_tile = (t0 - H >= 0 && t0 + T - 1 + H <= last);   // workgroup-uniform
+    const bool reflect = !inner_tile && n32 > 2 * H + 1;
+    if (reflect) {
+        const float m_first = (q0 <= 0) ? m_s[mpos(0 - q0)] : 0.f;
+        const float m_last = (last - q0 < T + 2 * H) ? m_s[mpos(last - q0)] : 0.f;
+        for (int s = tid; s < T + 2 * H; s += kThreads) {
+            const int q = q0 + s;
+            if (q < 0) m_s[mpos(s)] = 2.f * m_first - m_s[mpos(-q - q0)];
+            else if (q > last && q <= last + H) m_s[mpos(s)] = 2.f * m_last - m_s[mpos(2 * last - q - q0)];
+        }
+        __syncthreads();
+    }
+    if (inner_tile || reflect) {
         // out[r] = sum_t h[t] w[r + t], t = 0..80, w = m_s + o, two taps per packed FMA (lane 0: the
         // even t of the pair, lane 1: the odd one).  Even r: pairs (t, t+1) = (2j, 2j+1) sit on aligned
         // window pairs j + r/2.  Odd r: t = 0 alone, then pairs (t, t+1), t = 79 - 2j odd, whose taps
@@ -428,12 +444,18 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
                 wo[0] = wpair(H - 1 - j);
             }
         }
-        float4* dst = reinterpret_cast<float4*>(p_out + (int64_t)c * n + t0 + o);
-        dst[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
-        dst[1] = make_float4(acc[4].x + acc[4].y, acc[5].x + acc[5].y, acc[6].x + acc[6].y, acc[7].x + acc[7].y);
+        if (inner_tile || t0 + o + PER <= n32) {
+            float4* dst = reinterpret_cast<float4*>(p_out + (int64_t)c * n + t0 + o);
+            dst[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
+            dst[1] = make_float4(acc[4].x + acc[4].y, acc[5].x + acc[5].y, acc[6].x + acc[6].y, acc[7].x + acc[7].y);
+        } else {   // the channel ends inside this thread's run
+#pragma unroll
+            for (int r = 0; r < PER; ++r)
+                if (t0 + o + r < n32) p_out[(int64_t)c * n + t0 + o + r] = acc[r].x + acc[r].y;
+        }
         return;
     }
-    // edge tiles: odd reflection of m about the first / last sample (scipy filtfilt, padtype="odd")
+    // channels shorter than the filter's reach (n <= 81): sample by sample
     auto tap = [&](int j) -> float {   // lag j >= 0
         const v2f pr = taps.pair[(H + j) >> 1];
         return ((H + j) & 1) ? pr.y : pr.x;

@@ -318,7 +318,11 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     X(12500, 25, 20, 25, 8000, 20, 20, 20, RCFM_LDS_CHAIN_T)     \
     X(12500, 25, 20, 25, 6250, 25, 10, 25, 640)     \
     X(10000, 20, 20, 25, 8000, 20, 20, 20, 512)     \
-    X(12000, 24, 20, 25, 8000, 20, 20, 20, 640)
+    X(12000, 24, 20, 25, 8000, 20, 20, 20, 640)     \
+    X(12500, 25, 20, 25, 5000, 20, 10, 25, 512)     \
+    X(10000, 20, 20, 25, 5000, 20, 10, 25, 512)     \
+    X(12000, 24, 20, 25, 6000, 24, 10, 25, 640)     \
+    X(8000, 20, 20, 20, 4000, 20, 10, 20, 512)
 
 const float2* twiddle_table(int n) {
     static std::mutex mu;

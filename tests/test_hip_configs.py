@@ -89,31 +89,43 @@ def test_run_all_a_not_multiple_of_four(rc, oracle, kind, A):
             assert rel_err(audio[c.index], want) <= TOL, (kind, buf, c.index)
 
 
-@pytest.mark.parametrize("kind,A,chunk", [("FM", 8000, 0), ("MFM", 8000, 0), ("FM", 8000, 7), ("MFM", 6250, 0),
-                                          ("FM", 5000, 0)])
-def test_run_all_narrowband_fm_geometry(rc, oracle, kind, A, chunk):
-    """cfg5's channel geometry (12.5 kHz channels, 12 kHz raster) at a reduced band: N = 1e6, 81 channels.
-    B = 12 500 -> A = 8000 / 6250 run the whole chain of a channel pair in one workgroup, every transform in LDS
-    (lds_chain.hip): odd channel count and chunks of 7 leave lone pair members; MFM adds the de-emphasis kernel and
-    its carried state (two buffers).  A = 5000 has no LDS instantiation and stays on the multi-pass launches
-    (B = 100 x 125, the 125 -> 40 ... decimation falls back to the generic path): both must agree with the reference
-    loop (tuner.py:151-161, fm.py:60-67, mfm.py:62-66)."""
-    N, B, C = 1_000_000, 12500, 81
-    centres = workloads.channel_grid(C, 12000)
+@pytest.mark.parametrize("kind,B,A,chunk", [
+    ("FM", 12500, 8000, 0), ("MFM", 12500, 8000, 0), ("FM", 12500, 8000, 7), ("MFM", 12500, 6250, 0),
+    ("MFM", 12500, 5000, 7), ("FM", 10000, 8000, 7), ("MFM", 10000, 5000, 0), ("MFM", 12000, 8000, 0),
+    ("FM", 12000, 6000, 7), ("MFM", 8000, 4000, 7), ("FM", 12500, 4000, 0)])
+def test_run_all_narrowband_fm_geometry(rc, oracle, kind, B, A, chunk):
+    """cfg5's channel geometry (12.5 kHz channels, 12 kHz raster) and its neighbours at a reduced band: N = 1e6, 81
+    channels.  Every (B, A) of lds_chain.hip's table (12 500 -> 8000 / 6250 / 5000, 10 000 -> 8000 / 5000,
+    12 000 -> 8000 / 6000, 8000 -> 4000) runs the whole chain of a channel pair in one workgroup, every transform in
+    LDS: odd channel count and chunks of 7 leave lone pair members; MFM adds the de-emphasis kernel and its carried state
+    (two buffers).  12 500 -> 4000 has no LDS instantiation and stays on the multi-pass launches (B = 100 x 125): both
+    must agree with the reference loop (tuner.py:151-161, fm.py:60-67, mfm.py:62-66).  The stage profile says which
+    path ran."""
+    from radiocore._internal import hip
+    lib = hip.lib()
+    N, C = 1_000_000, 81
+    centres = workloads.channel_grid(C, int(0.96 * B))
     tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
-    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.1, stereo=False, deviation=2500.0)
-    for buf in range(2 if kind == "MFM" else 1):
-        xb = np.roll(x, 4242 * buf)
-        tuner.load(xb)
-        ref.load(xb)
-        audio = tuner.run_all(chunk=chunk)
-        assert audio.shape == (C, A, 1)
-        for c in ref.channels():
-            iq = ref.run_pruned(c.index)
-            if c.index in (0, 40, 80) and buf == 0:
-                assert rel_err(tuner.run(c.index), iq) <= TOL, c.index
-            want = np.asarray(c.demodulator.run(iq)).reshape(A, 1)
-            assert rel_err(audio[c.index], want) <= TOL, (kind, A, buf, c.index, rel_err(audio[c.index], want))
+    x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.1, stereo=False, deviation=0.2 * B)
+    hip.check(lib.rcfm_profile_enable((1 << lib.rcfm_profile_stage_count()) - 1))
+    hip.check(lib.rcfm_profile_reset())
+    try:
+        for buf in range(2 if kind == "MFM" else 1):
+            xb = np.roll(x, 4242 * buf)
+            tuner.load(xb)
+            ref.load(xb)
+            audio = tuner.run_all(chunk=chunk)
+            assert audio.shape == (C, A, 1)
+            for c in ref.channels():
+                iq = ref.run_pruned(c.index)
+                if c.index in (0, 40, 80) and buf == 0:
+                    assert rel_err(tuner.run(c.index), iq) <= TOL, c.index
+                want = np.asarray(c.demodulator.run(iq)).reshape(A, 1)
+                assert rel_err(audio[c.index], want) <= TOL, (kind, B, A, buf, c.index, rel_err(audio[c.index], want))
+        ran = _stages_run(lib, hip)
+    finally:
+        hip.check(lib.rcfm_profile_enable(0))
+    assert (ran["lds_chain"] > 0) == ((B, A) != (12500, 4000)), ran
 
 
 def test_lds_chain_pairing_does_not_matter(rc, oracle):
