@@ -149,8 +149,11 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *   RCFM_OPT_FUSED_TILES  two transforms per tile: pilot chain, Hilbert mask, stereo mix, spectral decimation between
  *                         transforms (0: one transform per launch, the intermediate spectra go through memory)
  *   RCFM_OPT_PHASE_LINK   the tuner hands the demodulator angle(x) / pi as float32 (0: complex64 samples, as
- *                         tuner.py:161 returns them) */
-enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3 };
+ *                         tuner.py:161 returns them)
+ *   RCFM_OPT_NARROW_TILES the tile kernels exist with 16 and with 8 lines per tile: 0 = always 16, 1 (default) = 8 when a
+ *                         launch has fewer than two 16-line tiles per CU (one WBFM.run per call, the reference's harness
+ *                         shape tests/benchmark.py:29-31: 60 short tiles instead of 30 long ones), 2 = always 8 */
+enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 

@@ -21,6 +21,10 @@
 #include "kernels.h"
 #include "lds_chain.h"
 
+// A fused_* function in the tile width the launch deserves (csrc/tile_ns.h): 16 lines per tile for batches, 8 for a
+// handful of channels.
+#define TILE_CALL(narrow_tiles, fn, ...) ((narrow_tiles) ? ::rcfm::narrow::fn(__VA_ARGS__) : ::rcfm::fn(__VA_ARGS__))
+
 namespace rcfm {
 
 namespace {
@@ -253,6 +257,25 @@ using namespace rcfm;
 // ---------------------------------------------------------------------------
 
 // RCFM_FFT=rocfft routes every transform through rocFFT (A/B runs and a safety net).
+// RCFM_NARROW_TILES (environment, read once; per demodulator handle: rcfm_demod_set_option): 0 = every tile kernel with 16
+// lines per tile, 1 (default) = 8 lines when a launch would leave most CUs without a tile, 2 = always 8.
+static int narrow_default() {
+    static const int v = [] {
+        const char* e = std::getenv("RCFM_NARROW_TILES");
+        return e ? std::atoi(e) : 1;
+    }();
+    return v;
+}
+// One tile per CU and a half-empty chip: that is where a launch lasts one tile's latency and narrower tiles (twice as
+// many, half the threads each) shorten it.  From two 16-line tiles per CU on, the wide ones stream better.
+static bool narrow_launch(const FftEngine& e, int signals, int mode = -1) {
+    if (mode < 0) mode = narrow_default();
+    if (mode == 0) return false;
+    if (mode >= 2) return true;
+    const int64_t tiles = (e.desc().pass[0].n_inner + kFftTileW - 1) / kFftTileW;
+    return (int64_t)signals * tiles < 2 * (int64_t)FftEngine::compute_units();
+}
+
 static bool use_engine() {
     static const bool v = [] {
         const char* e = std::getenv("RCFM_FFT");
@@ -429,7 +452,8 @@ struct rcfm_tuner_s {
             TunerGather tg{spectrum(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode,
                            halo ? base_dev.as<int32_t>() + first : nullptr, halo};
             StageTimer tm(ST_TUNER_IFFT, s);
-            fused_tuner_ifft(*bd.engine, tg, out, band_tmp.as<float2>(), count, s, theta, theta_pitch);
+            TILE_CALL(narrow_launch(*bd.engine, count), fused_tuner_ifft, *bd.engine, tg, out, band_tmp.as<float2>(), count, s,
+                      theta, theta_pitch);
             return;
         }
         RC_REQUIRE(theta == nullptr, RCFM_ERR_STATE, "phase output needs the FFT engine");
@@ -482,6 +506,8 @@ struct rcfm_demod_s {
     bool opt_lds_chain = env_default_on("RCFM_LDS_CHAIN");
     bool opt_fused_tiles = env_default_on("RCFM_PILOT_CHAIN") && env_default_on("RCFM_DECIM_TILE");
     bool opt_phase_link = env_default_on("RCFM_PHASE_LINK");
+    int opt_narrow = narrow_default();   // RCFM_OPT_NARROW_TILES
+    bool narrow(int cnt) const { return eng_B && narrow_launch(*eng_B, cnt, opt_narrow); }
     DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2, buf_dc;
     int tiles = 0;
 
@@ -621,6 +647,7 @@ struct rcfm_demod_s {
     void run_chunk(int first, int cnt, const float2* iq, float* audio, hipStream_t s, const float* theta = nullptr,
                    PhaseRows rows = PhaseRows{}) {
         size_t need = 0;
+        const bool nw = narrow(cnt);   // 8-line tiles for a handful of channels (tile_ns.h)
         if (kind == RCFM_WBFM) {
             FftPlan* pf[4] = {nullptr, nullptr, nullptr, nullptr};
             if (!eng_B) {
@@ -653,39 +680,39 @@ struct rcfm_demod_s {
                 // additionally one inverse FFT per channel (A/B testing of the fused forms)
                 static const bool unpacked = std::getenv("RCFM_HILBERT_UNPACK") != nullptr;
                 const bool no_chain = !opt_fused_tiles;
-                const bool chain = eng_Bi && !unpacked && !no_chain && fused_pilot_chain_applies(*eng_B, *eng_Bi, cnt);
-                const bool packed = eng_Bi && opt_fused_tiles && !unpacked && fused_hilbert_packed_applies(*eng_Bi, *eng_B, cnt);
+                const bool chain = eng_Bi && !unpacked && !no_chain && TILE_CALL(nw, fused_pilot_chain_applies, *eng_B, *eng_Bi, cnt);
+                const bool packed = eng_Bi && opt_fused_tiles && !unpacked && TILE_CALL(nw, fused_hilbert_packed_applies, *eng_Bi, *eng_B, cnt);
                 bool paired = false;
                 if (chain) {
                     {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
                         StageTimer tm(ST_FFT_REAL_B, s);
-                        fused_pilot_chain_fft_first(*eng_B, p, T, cnt, s);
+                        TILE_CALL(nw, fused_pilot_chain_fft_first, *eng_B, p, T, cnt, s);
                     }
                     {   // ... last pass, one-sided mask, inverse FFT, stereo matrix, first pass of the packed L/R FFT
                         StageTimer tm(ST_IFFT_B, s);
-                        fused_pilot_chain_mask_mix(*eng_B, *eng_Bi, p, m, T, buf_Ti.as<float2>(), cnt, s);
+                        TILE_CALL(nw, fused_pilot_chain_mask_mix, *eng_B, *eng_Bi, p, m, T, buf_Ti.as<float2>(), cnt, s);
                     }
                     paired = true;
                 } else {
                     {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
                         StageTimer tm(ST_FFT_REAL_B, s);
-                        fused_real_pair_fft(*eng_B, p, U2, T, cnt, packed ? kKeepLowerHalf : -1, s);
+                        TILE_CALL(nw, fused_real_pair_fft, *eng_B, p, U2, T, cnt, packed ? kKeepLowerHalf : -1, s);
                     }
                     if (eng_Bi && opt_fused_tiles) {
                         // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
                         // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
                         StageTimer tm(ST_IFFT_B, s);
-                        paired = !packed ? fused_hilbert_pair_ifft_mix_fft(*eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s)
-                                         : fused_hilbert_packed_ifft_mix_fft(*eng_Bi, *eng_B, U2, p, m,
+                        paired = !packed ? TILE_CALL(nw, fused_hilbert_pair_ifft_mix_fft, *eng_Bi, *eng_B, U2, m, buf_Ti.as<float2>(), T, cnt, s)
+                                         : TILE_CALL(nw, fused_hilbert_packed_ifft_mix_fft, *eng_Bi, *eng_B, U2, p, m,
                                                                              buf_Ti.as<float2>(), T, cnt, s);
                     }
                 }
                 const bool no_decim = !opt_fused_tiles;
-                if (paired && eng_Ad && !no_decim && fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, cnt)) {
+                if (paired && eng_Ad && !no_decim && TILE_CALL(nw, fused_fft_decim_ifft_applies, *eng_B, *eng_Ad, cnt)) {
                     const int pitch = audio_pitch();
                     {   // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
                         StageTimer tm(ST_FFT_B, s);
-                        fused_fft_decim_ifft(*eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
+                        TILE_CALL(nw, fused_fft_decim_ifft, *eng_B, *eng_Ad, T, V, TA, cnt, geom.wr.as<float>(), geom.scale,
                                              buf_dc.as<float2>(), s, pitch);
                     }
                     float* st = state_ptr() + (size_t)first * ch * 50;
@@ -695,20 +722,20 @@ struct rcfm_demod_s {
                 }
                 if (paired) {
                     StageTimer tm(ST_FFT_B, s);
-                    fused_fft_last_pruned(*eng_B, T, Z, cnt, std::min(A, B) / 2, s);
+                    TILE_CALL(nw, fused_fft_last_pruned, *eng_B, T, Z, cnt, std::min(A, B) / 2, s);
                 } else {
                     {   // one-sided mask -> inverse FFT -> 38 kHz carrier, L-R, stereo matrix (wbfm.py:83,86-87)
                         StageTimer tm(ST_IFFT_B, s);
-                        fused_hilbert_pair_ifft_mix(*eng_B, U2, m, Z, T, cnt, s);
+                        TILE_CALL(nw, fused_hilbert_pair_ifft_mix, *eng_B, U2, m, Z, T, cnt, s);
                     }
                     {   // both stereo legs in one complex FFT; only |k| <= A/2 survives the decimation
                         StageTimer tm(ST_FFT_B, s);
-                        fused_fft_pruned(*eng_B, Z, Z, T, cnt, std::min(A, B) / 2, s);
+                        TILE_CALL(nw, fused_fft_pruned, *eng_B, Z, Z, T, cnt, std::min(A, B) / 2, s);
                     }
                 }
                 {   // unpack + window + Nyquist rule ride on the first pass of IFFT_A
                     StageTimer tm(ST_IFFT_A, s);
-                    fused_stereo_unpack_ifft(*eng_A, Z, B, V, TA, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
+                    TILE_CALL(nw, fused_stereo_unpack_ifft, *eng_A, Z, B, V, TA, cnt, geom.wr.as<float>(), geom.nyq, geom.nmin,
                                              geom.nyq_factor, geom.scale, buf_dc.as<float2>(), s);
                     // -> [cnt][A][2] float32, L/R interleaved
                 }
@@ -772,18 +799,18 @@ struct rcfm_demod_s {
         }
         const bool no_decim_pairs = !opt_fused_tiles;
         if (eng_B && eng_Ad && !no_decim_pairs && ((int64_t)A % 4 == 0 || kind == RCFM_FM) &&
-            fused_fft_decim_ifft_applies(*eng_B, *eng_Ad, (cnt + 1) / 2)) {
+            TILE_CALL(nw, fused_fft_decim_ifft_applies, *eng_B, *eng_Ad, (cnt + 1) / 2)) {
             // two channels per complex signal from the pair FFT through the decimation to the inverse FFT:
             // 3 launches, no B-point spectrum in memory, half the inverse transforms
             {
                 StageTimer tm(ST_FFT_REAL_B, s);
-                fused_real_pair_fft_first(*eng_B, theta != nullptr ? theta : d, buf_T.as<float2>(), cnt,
+                TILE_CALL(nw, fused_real_pair_fft_first, *eng_B, theta != nullptr ? theta : d, buf_T.as<float2>(), cnt,
                                           theta != nullptr, s, rows);
             }
             float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
             {
                 StageTimer tm(ST_IFFT_A, s);
-                fused_fft_decim_ifft_pairs(*eng_B, *eng_Ad, buf_T.as<float2>(), dst, buf_TA.as<float2>(), cnt,
+                TILE_CALL(nw, fused_fft_decim_ifft_pairs, *eng_B, *eng_Ad, buf_T.as<float2>(), dst, buf_TA.as<float2>(), cnt,
                                            geom.wr.as<float>(), geom.scale, buf_dc.as<float2>(), s);
             }
             if (kind == RCFM_FM) return;
@@ -799,9 +826,9 @@ struct rcfm_demod_s {
                 // two channels per complex FFT; only |k| <= A/2 is kept (and read back by the unpacking).
                 // From the tuner's phases the discriminator is the load of the first pass.
                 if (theta != nullptr)
-                    fused_real_pair_fft(*eng_B, theta, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s, true, rows);
+                    TILE_CALL(nw, fused_real_pair_fft, *eng_B, theta, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s, true, rows);
                 else
-                    fused_real_pair_fft(*eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
+                    TILE_CALL(nw, fused_real_pair_fft, *eng_B, d, Dfull, buf_T.as<float2>(), cnt, std::min(A, B) / 2, s);
             }
             {
                 StageTimer tm(ST_AUDIO_SPECTRUM, s);
@@ -811,7 +838,7 @@ struct rcfm_demod_s {
             float* dst = (kind == RCFM_FM) ? audio : buf_v.as<float>();
             {
                 StageTimer tm(ST_IFFT_A, s);
-                fused_ifft_real_out(*eng_A, Yfull, dst, buf_TA.as<float2>(), cnt, 1.0f, s);
+                TILE_CALL(nw, fused_ifft_real_out, *eng_A, Yfull, dst, buf_TA.as<float2>(), cnt, 1.0f, s);
             }
             if (kind == RCFM_FM) return;
             float* st = state_ptr() + (size_t)first * 50;
@@ -1271,6 +1298,10 @@ int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
             case RCFM_OPT_LDS_CHAIN: d->opt_lds_chain = value != 0; break;
             case RCFM_OPT_FUSED_TILES: d->opt_fused_tiles = value != 0; break;
             case RCFM_OPT_PHASE_LINK: d->opt_phase_link = value != 0; break;
+            case RCFM_OPT_NARROW_TILES:
+                RC_REQUIRE(value >= 0 && value <= 2, RCFM_ERR_ARG, "narrow tiles: 0 never, 1 automatic, 2 always");
+                d->opt_narrow = value;
+                break;
             default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown demodulator option");
         }
     });

@@ -13,6 +13,7 @@
 #include "fft_kernel.h"
 
 namespace rcfm {
+RCFM_NS_OPEN
 
 // decimate.py:48 for the packed stereo pair between FFT_B's last pass and IFFT_A's first pass
 // (k_fft_tile2_decim): u = l + j r is one complex signal and the Hamming weight is real and even, so
@@ -48,7 +49,7 @@ template <int R, int T>
 __device__ __forceinline__ void stage_rt(float2* tile, const float2* tw, int L2, int mt, int tid) {
     const int m = mt / R, step = L2 / mt, nb = (L2 / R) * W;
     for (int e = tid; e < nb; e += T) {
-        const int w = e & (W - 1), b = e >> 4;
+        const int w = e & (W - 1), b = e >> kLogW;
         const int g = b / m, kp = b - g * m;
         const int base = g * mt + kp;
         float2 v[R];
@@ -68,7 +69,7 @@ constexpr bool decim_rt_radix_ok(int r) {
 }
 
 template <int L, int R0, int R1, int R2, int R3, int T>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim_rt(FftPassDev d1, FftPassDev d2,
+__global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_decim_rt(FftPassDev d1, FftPassDev d2,
                                                                               LoadPlainT<false> load, WinAudioDecim win,
                                                                               StorePlainT<false> store) {
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim_rt(Ff
     const FftPass& p2 = d2.p;
     const int L2 = p2.L;
     const int tid = threadIdx.x;
-    const int w = tid & (W - 1), rg = tid >> 4;
+    const int w = tid & (W - 1), rg = tid >> kLogW;
 
     LineId id;
     const BlockPos bp = block_pos();
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim_rt(Ff
 
     // ---- weights, Nyquist merge, swap for the inverse transform ----------------------------------------
     for (int e = tid; e < L2 * W; e += T) {
-        const int l = e >> 4, wl = e & (W - 1);
+        const int l = e >> kLogW, wl = e & (W - 1);
         float2 x = tile[lds_slot<true>(l, wl)];
         if (l == L2 / 2 && i0 + wl == 0) {   // Y[A/2] = X[A/2] + X[-A/2] (one point of one tile)
             const float2 y = tile[lds_slot<true>(L2, wl)];
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim_rt(Ff
     const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
     if (w < wvalid) {
         for (int e = tid; e < L2 * W; e += T) {
-            const int k = e >> 4;
+            const int k = e >> kLogW;
             const int row = d2.pos[k];
             const float2 y = cmul(tile[lds_slot<true>(row, w)], big_twiddle(d2, f * (unsigned)k));
             store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, y);
@@ -261,8 +262,9 @@ inline bool fft_tile2_decim_rt_applies(const FftPassDev& d1, const FftPassDev& d
 
 }  // namespace fftk
 
-// Defined in fused_decim.hip (its own translation unit: nineteen kernels).
+// Defined in fused_decim.hip (its own translation unit: nineteen kernels per tile width).
 bool launch_fft_tile2_decim_rt(const FftPassDev& d1, const FftPassDev& d2, int batch, const float2* tmp_f,
                                const WinAudioDecim& win, float2* tmp_a, hipStream_t s);
 
+RCFM_NS_CLOSE
 }  // namespace rcfm

@@ -24,6 +24,7 @@
 #pragma once
 
 namespace rcfm {
+RCFM_NS_OPEN
 namespace fftk {
 
 #ifndef RCFM_FFT_DMA_NT
@@ -329,4 +330,5 @@ __global__ __launch_bounds__(1024, 4) void k_fft_tile_dma(FftPassDev d, const fl
 }
 
 }  // namespace fftk
+RCFM_NS_CLOSE
 }  // namespace rcfm

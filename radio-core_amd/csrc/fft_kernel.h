@@ -24,12 +24,16 @@
 #include <type_traits>
 
 #include "fft_engine.h"
+#include "tile_ns.h"
 
 namespace rcfm {
+RCFM_NS_OPEN
 namespace fftk {
 
-constexpr int kThreads = 256;
-constexpr int W = kFftTileW;
+constexpr int W = RCFM_TILE_W;                 // lines per tile (tile_ns.h)
+constexpr int kLogW = W == 16 ? 4 : W == 8 ? 3 : 2;
+static_assert((1 << kLogW) == W, "tile width: 4, 8 or 16 lines");
+constexpr int kThreads = 256 * W / 16;
 
 // Complex product.  RCFM_ASM_CMUL: two packed instructions whose op_sel / neg modifiers pick the
 // halves (a.x b, then a.y (-b.y, b.x) + ...) -- the compiler's own packing builds those operand
@@ -686,7 +690,7 @@ constexpr bool triple_tile(int L) { return RCFM_FFT_TRIPLE400 && L == 400; }
 // `vgrid` (RCFM_FFT_PERSIST): no workgroup dispatch between the tiles of a CU, the next tile's loads are issued right
 // behind the stores of the previous one.
 template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp, bool PERSIST = false>
-__global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
+__global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
                                                                                           StoreOp store, dim3 vgrid) {
     // BIG: two 1024-thread workgroups per CU -- the tile is the whole LDS budget of the workgroup (80 KiB), so the
     // stage twiddles come from the table in global memory (twiddle_powers) and rows tiles use the XOR swizzle.
@@ -709,7 +713,7 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T >
     for (unsigned vid = PERSIST ? blockIdx.x : 0u; vid < vtotal; vid += PERSIST ? gridDim.x : 1u) {
     int tid = threadIdx.x;
     if constexpr (PERSIST) asm volatile("" : "+v"(tid));   // per-thread index tables (e / L, e % L per load) stay in the loop
-    const int w = tid & (W - 1), rg = tid >> 4;
+    const int w = tid & (W - 1), rg = tid >> kLogW;
     const VBlock vb = PERSIST ? vblock_of(vid, vgrid.x, vgrid.y, vgrid.z) : vblock_hw();
     LineId id;
     const BlockPos bp = block_pos(vb);
@@ -944,7 +948,7 @@ struct mid_upper_rows_zero<T, std::void_t<decltype(T::kUpperRowsZero)>> : std::b
 //
 // MidOp contract: kAux + fetch_aux(id, k, base, off) like StoreOp; float2 operator()(id, k, v, aux).
 template <int L, int R0, int R1, int R2, int R3, int T, class LoadOp, class MidOp, class StoreOp>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev d1, FftPassDev d2, LoadOp load,
+__global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev d1, FftPassDev d2, LoadOp load,
                                                                      MidOp mid, StoreOp store) {
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
@@ -957,7 +961,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
     const FftPass& p1 = d1.p;
     const FftPass& p2 = d2.p;
     const int tid = threadIdx.x;
-    const int w = tid & (W - 1), rg = tid >> 4;
+    const int w = tid & (W - 1), rg = tid >> kLogW;
 
     LineId id;
     const BlockPos bp = block_pos();
@@ -1125,7 +1129,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2(FftPassDev 
 //   float2 first(w, In0, Keep&)      member 0's value; Keep = what member 1 needs later
 //   float2 second(Keep, float)       member 1's value
 template <int L, int R0, int R1, int R2, int R3, int T, class LoadOp, class MidOp, class StoreOp>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPassDev d1, FftPassDev d2, LoadOp load,
+__global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPassDev d1, FftPassDev d2, LoadOp load,
                                                                           MidOp mid, StoreOp store, int count) {
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
@@ -1138,7 +1142,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
     const FftPass& p1 = d1.p;
     const FftPass& p2 = d2.p;
     const int tid = threadIdx.x;
-    const int w = tid & (W - 1), rg = tid >> 4;
+    const int w = tid & (W - 1), rg = tid >> kLogW;
 
     LineId id;
     const BlockPos bp = block_pos();
@@ -1331,7 +1335,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_pair(FftPas
 // WinOp contract: float weight(id, l, k0) (issued with the tile's loads), void dc_bin(id, float2 v0) receives
 // the weighted bin kappa = 0.
 template <int L, int R0, int R1, int R2, int R3, int L2, int Q0, int Q1, int T, class LoadOp, class WinOp, class StoreOp>
-__global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPassDev d1, FftPassDev d2, LoadOp load,
+__global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPassDev d1, FftPassDev d2, LoadOp load,
                                                                            WinOp win, StoreOp store) {
     constexpr int S = (R0 > 1) + (R1 > 1) + (R2 > 1) + (R3 > 1);
     static_assert(S >= 2 && R0 * R1 * R2 * R3 == L, "bad radix list");
@@ -1346,7 +1350,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
     const FftPass& p1 = d1.p;
     const FftPass& p2 = d2.p;
     const int tid = threadIdx.x;
-    const int w = tid & (W - 1), rg = tid >> 4;
+    const int w = tid & (W - 1), rg = tid >> kLogW;
 
     LineId id;
     const BlockPos bp = block_pos();
@@ -1392,7 +1396,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
         int e = tid + T * it;
         if ((L2 * W) % T != 0) e = e < L2 * W ? e : 0;
         const int wl = e & (W - 1);
-        wgt[it] = win.weight(id, e >> 4, i0 + (wl < wvalid ? wl : 0));
+        wgt[it] = win.weight(id, e >> kLogW, i0 + (wl < wvalid ? wl : 0));
     }
     for (int e = tid; e < L; e += T) tw[e] = d1.stage_tw[e];
 #pragma unroll
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
     for (int it = 0; it < nwin; ++it) {
         const int e = tid + T * it;
         if ((L2 * W) % T == 0 || e < L2 * W) {
-            const int l = e >> 4, wl = e & (W - 1);
+            const int l = e >> kLogW, wl = e & (W - 1);
             float2 x = tile[lds_slot<true>(l, wl)];
             if (l == L2 / 2 && i0 + wl == 0) {   // Y[A/2] = X[A/2] + X[-A/2] (one point of one tile)
                 const float2 y = tile[lds_slot<true>(L2, wl)];
@@ -1506,7 +1510,7 @@ __global__ __launch_bounds__(T, (T >= 512 ? 4 : 1)) void k_fft_tile2_decim(FftPa
 // RCFM_FFT_NT: 1 = non-temporal loads, 2 = non-temporal stores, 3 = both.  Measured on MI355X
 // (c2c 256 x 240000 / N = 2.4e8): stores +3 % / +2 %, loads -7 % / -2 %: stores only.
 #ifndef RCFM_FFT_NT
-#define RCFM_FFT_NT 2
+#define RCFM_FFT_NT (RCFM_TILE_W == 16 ? 2 : 0)   // (non-temporal stores are for whole 128-byte segments only: DESIGN.md section 8)
 #endif
 
 __device__ __forceinline__ float2 stream_load(const float2* p) {
@@ -1577,9 +1581,11 @@ struct StoreRowWindow {
 };
 
 }  // namespace fftk
+RCFM_NS_CLOSE
 }  // namespace rcfm
 #include "fft_dma.h"
 namespace rcfm {
+RCFM_NS_OPEN
 namespace fftk {
 
 // Lengths with a compile-time specialisation (radices listed first stage first; they must
@@ -1658,8 +1664,9 @@ namespace fftk {
 #ifndef RCFM_FFT_600_THREADS
 #define RCFM_FFT_600_THREADS 1024
 #endif
-constexpr int tile_threads(int L) {
-    return L == 600 ? RCFM_FFT_600_THREADS : (L > kFftMaxL || big_tile_pair(L)) ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256;
+constexpr int tile_threads(int L) {   // (RG = T / W butterfly rows per sweep is the same for every tile width)
+    return (L == 600 ? RCFM_FFT_600_THREADS : (L > kFftMaxL || big_tile_pair(L)) ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256) *
+           W / 16;
 }
 
 // Big tiles are instantiated for the plain functors only (the streaming passes of long transforms).
@@ -1721,7 +1728,7 @@ template <int LEN, int A, int B, int C, int D, bool ROWS, class LoadOp, class St
 inline void launch_fft_tile_one(const FftPassDev& d, dim3 grid, const LoadOp& ld, const StoreOp& st, hipStream_t s) {
     constexpr int T = tile_threads(LEN);
     constexpr bool kResidentTile = big_tile_pair(LEN) || triple_tile(LEN);
-    if constexpr (big_tile_pair(LEN) && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value &&
+    if constexpr (W == 16 && big_tile_pair(LEN) && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value &&
                   (!ROWS || LEN % 8 == 0)) {
         if (fft_dma_applies<LEN, ROWS>(d, grid, ld.in)) {
             const unsigned cus = (unsigned)FftEngine::compute_units() & ~7u;
@@ -1785,7 +1792,7 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
             RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
             default: break;
         }
-        if constexpr (is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
+        if constexpr (W == 16 && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
             switch (d.p.L) {
                 RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
@@ -1794,8 +1801,10 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
         }
     }
     if (!done)
-        hipLaunchKernelGGL((k_fft_pass<LoadOp, StoreOp>), FftEngine::grid(d.p, batch), dim3(kThreads),
-                           FftEngine::lds_bytes(d.p.L), s, d, ld, st);
+        hipLaunchKernelGGL((k_fft_pass<LoadOp, StoreOp>),
+                           dim3((unsigned)(d.p.n_o1 * d.p.n_o2 * ((d.p.n_inner + W - 1) / W)), (unsigned)batch, 1),
+                           dim3(kThreads), (size_t)d.p.L * (W * sizeof(float2) + sizeof(float2) + sizeof(uint16_t)), s, d,
+                           ld, st);
     RC_HIP(hipGetLastError());
 }
 
@@ -1899,4 +1908,5 @@ inline bool launch_fft_tile2(const FftPassDev& d1, const FftPassDev& d2, int bat
 }
 
 }  // namespace fftk
+RCFM_NS_CLOSE
 }  // namespace rcfm

@@ -2,6 +2,7 @@
 #include "fft_decim_rt.h"
 
 namespace rcfm {
+RCFM_NS_OPEN
 
 bool launch_fft_tile2_decim_rt(const FftPassDev& d1, const FftPassDev& d2, int batch, const float2* tmp_f,
                                const WinAudioDecim& win, float2* tmp_a, hipStream_t s) {
@@ -24,4 +25,5 @@ bool launch_fft_tile2_decim_rt(const FftPassDev& d1, const FftPassDev& d2, int b
     return true;
 }
 
+RCFM_NS_CLOSE
 }  // namespace rcfm

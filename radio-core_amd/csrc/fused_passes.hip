@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 namespace rcfm {
+RCFM_NS_OPEN
 
 using fftk::LineId;
 using fftk::kAnyPass;
@@ -727,6 +728,11 @@ void fused_fft_last_pruned(const FftEngine& e, const float2* tmp, float2* out, i
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
+static bool decim_rt(const FftPassDev& d1, const FftPassDev& d2, int batch, const float2* tmp_f, const WinAudioDecim& win,
+                     float2* tmp_a, hipStream_t s) {
+    return launch_fft_tile2_decim_rt(d1, d2, batch, tmp_f, win, tmp_a, s);
+}
+
 bool fused_fft_decim_ifft_applies(const FftEngine& ef, const FftEngine& ea, int count) {
     if (ef.npass() != 2 || ea.npass() != 2) return false;
     const int64_t B = ef.desc().n, A = ea.desc().n;
@@ -744,8 +750,7 @@ void fused_fft_decim_ifft(const FftEngine& ef, const FftEngine& ea, const float2
     fftk::StorePlainT<false> st{tmp_a, 1.0f};
     {   // the instantiated (L, L2) pairs first, then the kernel that takes L2 at run time
         const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), B), d2 = ea.pass_dev(0, A, ea.tmp_stride());
-        RC_REQUIRE(fftk::launch_fft_tile2_decim(d1, d2, count, ld, win, st, s) ||
-                       launch_fft_tile2_decim_rt(d1, d2, count, tmp_f, win, tmp_a, s),
+        RC_REQUIRE(fftk::launch_fft_tile2_decim(d1, d2, count, ld, win, st, s) || decim_rt(d1, d2, count, tmp_f, win, tmp_a, s),
                    RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
     }
     fftk::LoadPlainT<false> ldl{tmp_a};
@@ -797,8 +802,7 @@ void fused_fft_decim_ifft_pairs(const FftEngine& ef, const FftEngine& ea, const 
     fftk::StorePlainT<false> st{tmp_a, 1.0f};
     {
         const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), B), d2 = ea.pass_dev(0, A, ea.tmp_stride());
-        RC_REQUIRE(fftk::launch_fft_tile2_decim(d1, d2, pairs, ld, win, st, s) ||
-                       launch_fft_tile2_decim_rt(d1, d2, pairs, tmp_f, win, tmp_a, s),
+        RC_REQUIRE(fftk::launch_fft_tile2_decim(d1, d2, pairs, ld, win, st, s) || decim_rt(d1, d2, pairs, tmp_f, win, tmp_a, s),
                    RCFM_ERR_RUNTIME, "decimating two-transform kernel refused a pair it should accept");
     }
     fftk::LoadPlainT<false> ldl{tmp_a};
@@ -849,4 +853,5 @@ void fused_ifft_real_out(const FftEngine& e, const float2* Y, float* y, float2* 
     fftk::launch_fft_pass<kRowsOnly>(e.pass_dev(np - 1, e.tmp_stride(), n), count, ldl, stl, s);
 }
 
+RCFM_NS_CLOSE
 }  // namespace rcfm

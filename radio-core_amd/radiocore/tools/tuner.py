@@ -332,25 +332,29 @@ class Tuner(Injector):
             return None
         return kind, demod._input_size, demod._output_size, demod._tau
 
-    def set_kernel_options(self, lds_chain=True, fused_tiles=True, phase_link=True):
+    def set_kernel_options(self, lds_chain=True, fused_tiles=True, phase_link=True, narrow_tiles=1):
         """Which forms of the kernel chain run_all / run_each may use (rcfm_demod_set_option; no reference
         counterpart).  The audio does not depend on them beyond float32 rounding: switching all three off gives a
         second evaluation of the same path that shares no kernel schedule with the default one, which is what the
-        full-size parity tests compare against.  Takes effect with the next run_all / run_each."""
-        self._kernel_options = (bool(lds_chain), bool(fused_tiles), bool(phase_link))
+        full-size parity tests compare against.  narrow_tiles: 0 = tile kernels with 16 lines per tile always, 1 = 8 lines
+        when a launch has fewer than two tiles per CU (the default), 2 = always 8.  Takes effect with the next run_all /
+        run_each."""
+        self._kernel_options = (bool(lds_chain), bool(fused_tiles), bool(phase_link), int(narrow_tiles))
 
     def _batched_demod(self, kind, B, A, tau, chunk):
         # one handle per geometry, sized for all channels: rcfm_pipeline_run addresses the channels of tuner and
         # demodulator by the same index, so the per-channel state survives regrouping
-        opts = getattr(self, "_kernel_options", (True, True, True))
-        key = (kind, len(self._bounds), B, A, tau, int(chunk)) + ((opts,) if opts != (True, True, True) else ())
+        opts = getattr(self, "_kernel_options", (True, True, True, 1))
+        key = (kind, len(self._bounds), B, A, tau, int(chunk)) + ((opts,) if opts != (True, True, True, 1) else ())
         if key not in self._batched:
             h = ctypes.c_void_p()
             hip.check(self._lib.rcfm_demod_create(kind, len(self._bounds), B, A, tau, int(chunk), ctypes.byref(h)))
             self._batched[key] = hip.Handle(h, self._lib.rcfm_demod_destroy)
-            for opt, on in zip((hip.RCFM_OPT_LDS_CHAIN, hip.RCFM_OPT_FUSED_TILES, hip.RCFM_OPT_PHASE_LINK), opts):
+            for opt, on in zip((hip.RCFM_OPT_LDS_CHAIN, hip.RCFM_OPT_FUSED_TILES, hip.RCFM_OPT_PHASE_LINK), opts[:3]):
                 if not on:
                     hip.check(self._lib.rcfm_demod_set_option(h, opt, 0))
+            if opts[3] != 1:
+                hip.check(self._lib.rcfm_demod_set_option(h, hip.RCFM_OPT_NARROW_TILES, opts[3]))
             self._bind_states(key, self._batched[key])
         elif self._bound_version.get(key) != self._version:
             self._bind_states(key, self._batched[key])

@@ -489,3 +489,33 @@ def test_fused_chain_on_other_geometries(rc, oracle, kind, B, A):
     assert ran["audio_spectrum"] == 0, ran            # the decimation never ran as a kernel of its own
     if kind == "WBFM":
         assert ran["ifft_A"] == 0 and ran["fft_B"] > 0 and ran["hilbert_mask"] == 0 and ran["stereo_mix"] == 0, ran
+
+
+@pytest.mark.parametrize("narrow", [0, 2])
+@pytest.mark.parametrize("kind,B,A", [("FM", 60000, 12000), ("MFM", 60000, 12000), ("WBFM", 60000, 12000),
+                                      ("WBFM", 240000, 48000), ("WBFM", 256000, 32000), ("MFM", 375000, 37500)])
+def test_run_all_with_both_tile_widths(rc, oracle, kind, B, A, narrow):
+    """The tile kernels exist twice (csrc/tile_ns.h): 16 lines per tile for batches, 8 lines for a handful of channels
+    (chosen per launch: fewer than two 16-line tiles per CU).  Reduced-size tests would only ever see the narrow ones,
+    so this runs both on purpose (Tuner.set_kernel_options(narrow_tiles=0 / 2) -> rcfm_demod_set_option): every
+    demodulator, the cfg4 geometry, the reference's benchmark geometry (256 000 -> 32 000: the run-time-L2 decimating
+    kernel) and a three-pass band -- against the reference loop (multi_fm_server.py:100-106), odd channel count, two
+    buffers."""
+    C = 5 if B <= 60000 else 3
+    raster = int(1.2 * B)
+    N = (C + 1) * raster
+    centres = workloads.channel_grid(C, raster)
+    tuner, ref = _pair(rc, oracle, kind, centres, B, A, N)
+    tuner.set_kernel_options(narrow_tiles=narrow)
+    stereo = kind == "WBFM"
+    ch = 2 if stereo else 1
+    for buf in range(2):
+        x = workloads.wideband(N, ref.input_frequency, centres, B, gain=0.4, stereo=stereo,
+                               deviation=None if B < 300000 else 0.1 * B)
+        x = np.roll(x, 517 * buf)
+        tuner.load(x)
+        ref.load(x)
+        audio = tuner.run_all(chunk=2 if narrow else 0)
+        for c in ref.channels():
+            want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, ch)
+            assert rel_err(audio[c.index], want) <= TOL, (kind, B, A, narrow, buf, c.index, rel_err(audio[c.index], want))
