@@ -13,7 +13,7 @@ def per_step(path, steps):
     db = sqlite3.connect(path)
     rows = [r for r in db.execute("select name, total_calls, total_duration, average from top_kernels") if "rcfm::" in r[0]]
     total = sum(r[2] for r in rows)
-    print("rcfm:: kernels only; %d steps of the path in the traced process; sum = %.1f us per step" % (steps, total / 1e3 / steps))
+    print("rcfm:: kernels only; %d steps of the path in the traced process; sum = %.1f us per step" % (steps, total / steps))
     print()
     print("| kernel | launches per step | us per launch | us per step | % of the step |")
     print("|---|---:|---:|---:|---:|")
@@ -21,7 +21,7 @@ def per_step(path, steps):
         short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rcfm::fftk::", "").replace("rcfm::", "")
         if len(short) > 100:
             short = short[:97] + "..."
-        print("| `%s` | %.2f | %.2f | %.1f | %.1f |" % (short, calls / steps, avg, tot / 1e3 / steps, 100.0 * tot / total))
+        print("| `%s` | %.2f | %.2f | %.1f | %.1f |" % (short, calls / steps, avg, tot / steps, 100.0 * tot / total))
 
 
 def main(path, limit=40, only=None):
