@@ -122,3 +122,20 @@ def test_big_tiles_in_both_roles(n, plan, monkeypatch):
     want = np.fft.fft(x.astype(np.complex128), axis=1).astype(np.complex64)
     assert rel_err(_run(n, 2, False, x), want) <= 2e-6
     assert rel_err(_run(n, 2, True, want), x * n) <= 4e-6
+
+
+@pytest.mark.timeout(600)
+def test_lds_dma_streaming_passes_in_a_subprocess():
+    """The LDS-DMA form of the big-tile streaming passes (csrc/fft_dma.h: one persistent workgroup per CU, tile i+1
+    fetched by global_load_lds into the second LDS buffer while tile i is transformed, counted vmcnt waits) is not the
+    default -- it measured slower or equal, profiles/r04_a_lds_dma.md -- but it stays correct: RCFM_FFT_DMA is read once
+    per process, so tools/dma_check.py runs in its own (forced two-pass plans with 600 / 625 strided and 640 rows against
+    torch.fft, N = 1e8 and 2.4e8 against rocFFT)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RCFM_FFT_DMA="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dma_check.py")], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=550)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-2000:] + out.stderr[-2000:]
