@@ -756,18 +756,27 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
 __global__ __launch_bounds__(128) void k_fir_state(const float* __restrict__ x, int64_t n, int ch,
                                                    const float* __restrict__ taps, int nb,
                                                    float* __restrict__ state, RowLayout lay) {
+    // The last nb - 1 inputs and the taps go to LDS first (independent, coalesced loads); the triangular sums then run
+    // from LDS in the same order as before.  (Round 3 read x and the taps inside the sum: fifty dependent-latency global
+    // loads per thread, 5.9 us for a kernel that is the last launch of every MFM / WBFM call.)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* z_old = smem;  // nb - 1
+    float* z_old = smem;             // nb - 1
+    float* xt = smem + (nb - 1);     // xt[i] = x[n - 1 - i], i < nb - 1
+    float* tp = xt + (nb - 1);       // nb taps
     const int h = blockIdx.x % ch, c = blockIdx.x / ch;
     const float* xc = x + (int64_t)c * lay.signal_stride;
     float* zc = state + ((int64_t)c * ch + h) * (nb - 1);
-    for (int s = threadIdx.x; s < nb - 1; s += blockDim.x) z_old[s] = zc[s];
+    for (int s = threadIdx.x; s < nb - 1; s += blockDim.x) {
+        z_old[s] = zc[s];
+        xt[s] = (s < n) ? xc[lay.at((n - 1 - s) * ch + h)] : 0.f;
+    }
+    for (int s = threadIdx.x; s < nb; s += blockDim.x) tp[s] = taps[s];
     __syncthreads();
     for (int s = threadIdx.x; s < nb - 1; s += blockDim.x) {
         // zf[s] = sum_i b[s+1+i] x[n-1-i]  (+ what is left of the old state when n < nb-1)
         float acc = 0.f;
-        const int64_t cnt = (nb - 1 - s) < n ? (nb - 1 - s) : n;
-        for (int64_t i = 0; i < cnt; ++i) acc = fmaf(taps[s + 1 + i], xc[lay.at((n - 1 - i) * ch + h)], acc);
+        const int cnt = (int)((nb - 1 - s) < n ? (nb - 1 - s) : n);
+        for (int i = 0; i < cnt; ++i) acc = fmaf(tp[s + 1 + i], xt[i], acc);
         if (s + n < nb - 1) acc += z_old[s + n];
         zc[s] = acc;
     }
@@ -960,7 +969,7 @@ void launch_fir51(const float* x, float* y, int64_t n, int ch, int batch, const 
 void launch_fir_state(const float* x, int64_t n, int ch, int batch, const float* taps, int nb,
                       float* state, hipStream_t stream, int row_samples, int row_pitch_samples) {
     if (batch <= 0 || nb < 2) return;
-    hipLaunchKernelGGL(k_fir_state, dim3((unsigned)(batch * ch)), dim3(128), sizeof(float) * (nb - 1), stream,
+    hipLaunchKernelGGL(k_fir_state, dim3((unsigned)(batch * ch)), dim3(128), sizeof(float) * (3 * nb), stream,
                        x, n, ch, taps, nb, state, row_layout(n, ch, row_samples, row_pitch_samples));
     RC_LAUNCH_CHECK();
 }
