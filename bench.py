@@ -48,6 +48,8 @@ CONFIGS = {
     # (tests/benchmark.py:85, WBFM(256e3, 32e3)) and a 200 kHz-channel band, batched like cfg4
     "geo256k": (240_000_000, 1024, 256_000, 32_000, 220_000, "WBFM"),
     "geo200k": (240_000_000, 1024, 200_000, 40_000, 200_000, "WBFM"),
+    # cfg5's band with MFM instead of FM: the LDS-resident chain plus the de-emphasis launches
+    "nbmfm": (100_000_000, 8192, 12_500, 8_000, 12_000, "MFM"),
 }
 
 # Algorithmic bytes of each stage per unit:
@@ -310,6 +312,7 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
         "roofline": roof,
         "output_finite": finite,
         "parity": ("tests/test_hip_configs.py::test_%s_full_size_%s" % (name, kind.lower()) if name.startswith("cfg") else
+                   "tests/test_hip_configs.py::test_run_all_narrowband_fm_geometry[MFM-12500-8000-0] (reduced band)" if name == "nbmfm" else
                    "tests/test_hip_configs.py::test_fused_chain_on_other_geometries[%s-%d-%d] (reduced band)" % (kind, B, A)),
     }
 
@@ -824,6 +827,7 @@ def main():
             "cfg2_batched": measure_batched_cfg2(lib, hip, 10, 2),
             "geo256k": measure_config("geo256k", lib, hip, 10, 2, with_surface=False),
             "geo200k": measure_config("geo200k", lib, hip, 10, 2, with_surface=False),
+            "nbmfm": measure_config("nbmfm", lib, hip, 10, 2, with_surface=False),
             "cfg2_single": measure_cfg2_single(),
             "cfg1_cpu": measure_cfg1_cpu(),
         }

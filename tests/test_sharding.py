@@ -89,3 +89,33 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     want = _audio_for(range(len(CENTRES)))
     assert got.shape == want.shape == (len(CENTRES), A, 1)
     assert np.array_equal(got, want)
+
+
+def _one_rank_worker(rank, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("RCFM_GATHER_FORCE_COLLECTIVE", None)
+    sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
+    from radiocore.tools import sharding
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    block = np.arange(24, dtype=np.float32).reshape(3, 4, 2)          # what run_all() returns by default: numpy
+    same = sharding.gather_audio(block, 3) is block                   # one rank: `local` IS the result
+    h = sharding.gather_audio(block, 3, async_op=True)
+    same = same and h.wait() is block
+    t = torch.arange(24, dtype=torch.float32).reshape(3, 4, 2)
+    out = torch.zeros_like(t)
+    got = sharding.gather_audio(t, 3, out=out)                        # an `out` buffer still receives the block
+    same = same and got is out and bool(torch.equal(out, t))
+    os.environ["RCFM_GATHER_FORCE_COLLECTIVE"] = "1"                  # the collective path on the same one-rank group
+    forced = sharding.gather_audio(t, 3)
+    same = same and forced is not t and bool(torch.equal(forced, t))
+    np.save(out_path, np.array([int(same)]))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_returns_the_local_block_untouched(tmp_path):
+    """gather_audio on a one-rank group (torch.distributed initialised, world size 1): no collective, no copy -- a numpy
+    block passes through like before round 3; RCFM_GATHER_FORCE_COLLECTIVE=1 is what the RCCL dry runs set."""
+    out = str(tmp_path / "one.npy")
+    mp.spawn(_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert np.load(out)[0] == 1

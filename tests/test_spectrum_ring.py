@@ -46,6 +46,8 @@ class FakeTuner:
         self.shard_range = (first, count)
 
     def window(self, n, first, count):
+        if count == 0:
+            return 0, 0                              # a rank without channels reads nothing (rcfm_tuner_window)
         rows = n // ROW
         used = np.zeros(rows, bool)
         for c in range(first, first + count):
@@ -99,15 +101,16 @@ def _buffer(i):
     return torch.complex(torch.randn(N, generator=g), torch.randn(N, generator=g)).to(torch.complex64)
 
 
-def _worker(rank, world, port, lookahead, buffers, out_dir):
+def _worker(rank, world, port, lookahead, buffers, out_dir, channels=C):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
     from radiocore.tools import sharding
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tuner = FakeTuner()
-    ring = sharding.SpectrumRing(tuner, N, C, lookahead=lookahead)
-    lo, hi = sharding.channel_range(rank, world, C)
+    ring = sharding.SpectrumRing(tuner, N, channels, lookahead=lookahead)
+    ring.enable_timing()
+    lo, hi = sharding.channel_range(rank, world, channels)
     assert tuner.shard_range == (lo, hi - lo)
     ok = True
     with pytest.raises(RuntimeError, match="after their submit"):
@@ -128,6 +131,9 @@ def _worker(rank, world, port, lookahead, buffers, out_dir):
         ring.submit(buffers + 5)
     owned = len([i for i in range(buffers) if i % world == rank])
     ok = ok and tuner.loads == owned                               # one FFT per owned buffer, none for the others
+    t = ring.timing_summary()                                      # what bench.py prints per rank for N > 1
+    ok = ok and t["fft_count"] == owned and t["send_count"] == owned and t["wait_count"] == buffers
+    ok = ok and t["fft_ms"] >= 0 and t["send_ms"] >= 0 and t["wait_ms"] >= 0
     dist.barrier()
     np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(ok), ring.bytes_sent_per_buffer()]))
     dist.destroy_process_group()
@@ -140,6 +146,18 @@ def test_rotating_owner_delivers_every_window(tmp_path, world, lookahead):
         ok, sent = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
         assert ok == 1, r
         assert 0 < sent < 8 * N * (world - 1)                      # windows, not whole spectra
+
+
+def test_more_ranks_than_channels(tmp_path):
+    """C = 2 channels on G = 3 ranks: rank 0 owns none (sharding.channel_range), reads an empty window, takes part in no
+    transfer and still walks the schedule (it owns every third buffer's FFT)."""
+    mp.spawn(_worker, args=(3, _free_port(), None, 7, str(tmp_path), 2), nprocs=3, join=True)
+    for r in range(3):
+        ok, sent = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
+        assert ok == 1, r
+    sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
+    from radiocore.tools.sharding import channel_range
+    assert channel_range(0, 3, 2) == (0, 0)
 
 
 def test_window_segments():
