@@ -1,6 +1,8 @@
 """GPU: whole-output parity at BASELINE's full sizes ("full-size parity is a thin sample").
 
-(a) EVERY channel of cfg4 / cfg5 `run_all()` against a second HIP evaluation that shares no kernel schedule with it:
+(a) EVERY channel of cfg4 / cfg5 / cfg3 `run_all()` -- and of two batched geometries off BASELINE's shape: 1024 x WBFM
+    256 000 -> 32 000 (the run-time-L2 decimating tile at full size) and 8192 x narrow-band MFM -- against a second HIP
+    evaluation that shares no kernel schedule with it:
     the channels added in reverse order (other pair partners, other tiles, other workgroups), other chunking, and the
     kernel chain with every fused form switched off through the API (`Tuner.set_kernel_options` ->
     rcfm_demod_set_option: no LDS-resident chain, no two-transforms-per-tile kernels, complex hand-over instead of the
@@ -84,7 +86,8 @@ def _worst(a, b):
     return (num / den).cpu().numpy()
 
 
-@pytest.mark.parametrize("name,buffers,chunk", [("cfg5", 1, 2048), ("cfg4", 2, 512)])
+@pytest.mark.parametrize("name,buffers,chunk", [("cfg5", 1, 2048), ("cfg4", 2, 512), ("cfg3", 2, 24), ("geo256k", 1, 256),
+                                                ("nbmfm", 2, 4096)])
 def test_every_channel_against_an_independent_hip_evaluation(rc, name, buffers, chunk):
     import torch
     N, C, B, A, kind, x, centres, f_in = _setup(rc, name)
