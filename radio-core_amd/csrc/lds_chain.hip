@@ -46,6 +46,10 @@ using fftk::twiddle_powers;
 #define RCFM_TRACE_POINT(i) do { } while (0)
 #endif
 
+#ifndef RCFM_LDS_CHAIN_FUSED_GATHER
+#define RCFM_LDS_CHAIN_FUSED_GATHER 1
+#endif
+
 struct ChainDev {
     long long* trace;             // RCFM_LDS_CHAIN_TRACE builds only
     LdsChainArgs a;
@@ -111,13 +115,26 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     // The B bins of one channel, raw, into registers: issued one phase AHEAD of their use (the member's loads fly
     // under the previous member's arctangents, the next pair's under this pair's IFFT_A) -- with one workgroup per CU
     // nothing else would hide the memory latency.
-    float2 v[NL], x2;
+    // RCFM_LDS_CHAIN_FUSED_GATHER (default): the bins arrive in the order the first stage of IFFT_B consumes them --
+    // thread b holds points b + q (B / R0), q < R0, of one radix-R0 butterfly -- so window, Nyquist merge and that stage
+    // run straight from the prefetched registers and xs is written once, already transformed: one LDS write + barrier +
+    // LDS read less per member than "gather to xs, then stage 1" (round 3).  The loads stay coalesced (lanes = adjacent b).
+    // (The 640-thread instantiations are capped at 168 VGPRs and spill another 200 dwords in this form: they keep round 3's.)
+    constexpr int M0 = B / R0;                                   // butterflies of the first stage
+    constexpr bool kFused = RCFM_LDS_CHAIN_FUSED_GATHER && T <= 512 && M0 <= T;
+    constexpr int NV = kFused ? R0 : NL;
+    float2 v[NV], x2;
     auto issue_gather = [&](int c) {
         const float2* Xc = p.a.X + p.a.base[c];
 #pragma unroll
-        for (int it = 0; it < NL; ++it) {
-            int k = tid + T * it;
-            k = k < B ? k : B - 1;                              // ragged last sweep: clamped, not stored
+        for (int it = 0; it < NV; ++it) {
+            int k;
+            if constexpr (kFused) {
+                k = (tid < M0 ? tid : M0 - 1) + M0 * it;         // (the surplus threads repeat the last butterfly's loads)
+            } else {
+                k = tid + T * it;
+                k = k < B ? k : B - 1;                          // ragged last sweep: clamped, not stored
+            }
             v[it] = Xc[k < p.a.nyq ? k : k - B];
         }
         x2 = Xc[p.a.merge >= 0 ? -p.a.merge : 0];               // Y[+B/2] += X[-B/2] w(-B/2) (NYQ_DOWN)
@@ -143,19 +160,42 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
             m2 = make_float2(x2.x * w2, x2.y * w2);
         }
         // (xs is free: member 0 starts behind the previous pair's closing barrier, member 1 behind the one below)
+        if constexpr (kFused) {
+            RCFM_TRACE_POINT(mem * 6 + 1);
+            if (tid < M0) {
+                const float2 w1 = p.twB[tid];                   // W_B^b: the first stage's twiddle of butterfly b
+                float2 u[R0];
 #pragma unroll
-        for (int it = 0; it < NL; ++it) {
-            const int k = tid + T * it;
-            if (k < B) {
-                const float w = window(k < p.a.nyq ? k : k - B);
-                const float sel = (k == p.a.merge) ? 1.f : 0.f;
-                xs[k] = make_float2(fmaf(sel, m2.y, v[it].y * w), fmaf(sel, m2.x, v[it].x * w));   // swapped
+                for (int q = 0; q < R0; ++q) {
+                    const int k = tid + M0 * q;
+                    const float w = window(k < p.a.nyq ? k : k - B);
+                    const float sel = (k == p.a.merge) ? 1.f : 0.f;
+                    u[q] = make_float2(fmaf(sel, m2.y, v[q].y * w), fmaf(sel, m2.x, v[q].x * w));   // swapped
+                }
+                dft_pa<R0>(u);
+                float2 pw[R0];
+                twiddle_powers<R0>(w1, pw);
+#pragma unroll
+                for (int q = 1; q < R0; ++q) u[dft_slot<R0>(q)] = cmul(u[dft_slot<R0>(q)], pw[q]);
+#pragma unroll
+                for (int q = 0; q < R0; ++q) xs[tid + M0 * q] = u[dft_slot<R0>(q)];
             }
+            lds_barrier();
+        } else {
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const int k = tid + T * it;
+                if (k < B) {
+                    const float w = window(k < p.a.nyq ? k : k - B);
+                    const float sel = (k == p.a.merge) ? 1.f : 0.f;
+                    xs[k] = make_float2(fmaf(sel, m2.y, v[it].y * w), fmaf(sel, m2.x, v[it].x * w));   // swapped
+                }
+            }
+            lds_barrier();
+            RCFM_TRACE_POINT(mem * 6 + 1);
+            chain_stage<B, R0, B, T>(xs, p.twB, tid);
+            lds_barrier();
         }
-        lds_barrier();
-        RCFM_TRACE_POINT(mem * 6 + 1);
-        chain_stage<B, R0, B, T>(xs, p.twB, tid);
-        lds_barrier();
         RCFM_TRACE_POINT(mem * 6 + 2);
         chain_stage<B, R1, B / R0, T>(xs, p.twB, tid);
         lds_barrier();
