@@ -610,6 +610,33 @@ struct rcfm_demod_s {
         return (n1 % 16 == 0 || (n1 * 2) % 4 != 0) ? 0 : (int)((n1 + 15) / 16 * 16);
     }
 
+    // Are the 51 taps the first samples of a one-pole impulse response (b[0] = 0, geometric tail)?  The same test
+    // launch_fir51 applies (kernels.hip): the recursive forms of the FIR rely on it.
+    bool deemph_geometric() const {
+        if (!(taps_h[0] == 0.f && taps_h[1] > 0.f)) return false;
+        for (int i = 1; i < 50; ++i)
+            if (std::fabs((double)taps_h[i + 1] * taps_h[1] - (double)taps_h[i] * taps_h[2]) >
+                4e-7 * (double)taps_h[i] * taps_h[1] + 1e-36)
+                return false;
+        return true;
+    }
+
+    // The taps followed by their suffix sums sfx[i] = sum_{j > i} b[j] (what the on-chip de-emphasis of lds_chain.hip reads).
+    DeviceBuffer taps_sfx;
+    const float* taps_sfx_dev() {
+        if (taps_sfx.bytes() == 0) {
+            float h[102];
+            for (int i = 0; i < 51; ++i) h[i] = taps_h[i];
+            double acc = 0.0;
+            for (int i = 50; i >= 0; --i) {
+                h[51 + i] = (float)acc;          // sum of b[j], j > i
+                acc += (double)taps_h[i];
+            }
+            taps_sfx.upload(h, sizeof(h));
+        }
+        return taps_sfx.as<float>();
+    }
+
     void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s, bool have_dc = false,
                     int row = 0, int pitch = 0) {
         const bool fast = ((int64_t)A * ch) % 4 == 0;
@@ -1343,16 +1370,27 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                     RC_REQUIRE(t->bw[first + off + i] == d->B, RCFM_ERR_SIZE, "input_sig size and input_size mismatch");
                 const ResampleGeom& tg = t->band(d->B).geom;
                 float* out_c = outp + (size_t)off * d->A;
-                float* dst = (d->kind == RCFM_FM) ? out_c : d->buf_v.as<float>();
+                // MFM: de-emphasis, mean removal and clip (mfm.py:62-66) run inside the same kernel when the taps are the
+                // one-pole response deemphasis.py:37-46 designs (always, unless a caller replaced them): only the audio
+                // leaves the chip.  Otherwise the chain stops at the decimated signal and the de-emphasis launches follow.
+                static const bool deemph_chain = env_default_on("RCFM_LDS_DEEMPH");   // =0: the de-emphasis launches (A/B runs)
+                const bool deemph_on_chip = d->kind == RCFM_MFM && deemph_chain && d->deemph_geometric() &&
+                                            lds_chain_deemph_supported(d->B, d->A);
+                float* dst = (d->kind == RCFM_FM || deemph_on_chip) ? out_c : d->buf_v.as<float>();
                 LdsChainArgs a{t->spectrum(), t->base_dev.as<int32_t>() + first + off, t->n, tg.nyq,
                                tg.nyq_mode == NYQ_DOWN ? tg.nyq - 1 : -1, d->geom.wr.as<float>(), d->geom.scale, dst,
                                d->buf_dc.as<float2>(), cnt};
+                if (deemph_on_chip) {
+                    a.deemph_taps = d->taps_sfx_dev();
+                    a.deemph_state = d->state_ptr() + (size_t)(first + off) * 50;
+                    a.dc = nullptr;
+                }
                 {
                     StageTimer tm(ST_LDS_CHAIN, as_stream(stream));
                     RC_REQUIRE(launch_lds_chain(d->B, d->A, a, as_stream(stream)), RCFM_ERR_RUNTIME,
                                "LDS chain refused a geometry it lists");
                 }
-                if (d->kind == RCFM_MFM)
+                if (d->kind == RCFM_MFM && !deemph_on_chip)
                     d->run_deemph(dst, out_c, d->state_ptr() + (size_t)(first + off) * 50, cnt, as_stream(stream), true);
                 continue;
             }

@@ -23,13 +23,20 @@ struct LdsChainArgs {
     // demodulator side: folded Hamming weights of Decimate(B -> A) (A/2 + 1 entries) and 1/B
     const float* wr;
     float scale;
-    float* audio;                 // [count][A] float32 (FM: the result; MFM: the de-emphasis kernel's input)
+    float* audio;                 // [count][A] float32 (FM: the result; MFM without deemph_taps: the de-emphasis kernel's input)
     float2* dc;                   // [count] or null: (mean of the channel's audio, 0) from the DC bin
     int count;
+    // MFM entirely on chip (mfm.py:62-66): the 51 de-emphasis taps (device; a one-pole response, deemphasis.py:37-46 --
+    // the caller checks) and the carried FIR state [count][50] (deemphasis.py:48-49,64: read, then replaced): `audio` then
+    // receives lfilter(taps, v, zi) - mean, clipped to +-0.999.  Null: the kernel stops at the decimated signal v.
+    const float* deemph_taps = nullptr;   // 102 floats: b[0..50], then sfx[i] = sum_{j > i} b[j], i = 0..50
+    float* deemph_state = nullptr;
 };
 
 // Is there an instantiation for B -> A?  (lengths listed in lds_chain.hip)
 bool lds_chain_supported(int B, int A);
+// Does the instantiation for B -> A also exist with MFM's de-emphasis inside (LdsChainArgs::deemph_taps)?
+bool lds_chain_deemph_supported(int B, int A);
 // Launches ceil(count / 2) workgroups; returns false (nothing launched) when (B, A) has no instantiation.
 bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream);
 

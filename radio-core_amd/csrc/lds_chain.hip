@@ -96,13 +96,24 @@ __device__ __forceinline__ int chain_last(const float2* x, int tid, float2* v) {
     return q1 + R0 * q2;
 }
 
-template <int B, int R0, int R1, int R2, int A, int Q0, int Q1, int Q2, int T>
+// DEEMPH: MFM -- the de-emphasis FIR with its carried state, mean removal and clip (mfm.py:62-66) run here as well, and the
+// audio that leaves the chip is final.  A separate instantiation: the FM kernel (cfg5) keeps its registers.
+template <int B, int R0, int R1, int R2, int A, int Q0, int Q1, int Q2, int T, bool DEEMPH>
 __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     static_assert(R0 * R1 * R2 == B && Q0 * Q1 * Q2 == A, "radix lists");
     static_assert(A % 2 == 0 && A < B && (size_t)B * 12 <= 160 * 1024, "geometry");
     __shared__ __attribute__((aligned(16))) float2 xs[B];
     __shared__ __attribute__((aligned(16))) float ds[B];
     float* const th1 = reinterpret_cast<float*>(xs) + B;      // member 1's phases: upper half of xs
+    // the tail of ds, behind the decimation weights (A/2 + 1 <= B - 256): de-emphasis taps [0, 51), carried state of
+    // member 0 [64, 114) and member 1 [128, 178), the two means [192, 194), the DC bins [200, 202), suffix sums of the
+    // taps [204, 255)
+    constexpr int kScratch = B - 256;
+    // MFM: the audio in xs is read back in runs of 32 consecutive samples per lane (the de-emphasis below); one pad slot
+    // every 32 samples puts adjacent lanes 33 slots = 66 dwords apart: conflict-free for every access of that phase.
+    auto aswz = [](int n) -> int { return DEEMPH ? n + (n >> 5) : n; };
+    static_assert(!DEEMPH || A + (A >> 5) + 1 <= B, "padded audio fits xs");
+    static_assert(A / 2 + 1 <= kScratch && T <= 1024, "scratch behind the decimation weights");
     int tid = threadIdx.x;
     const int npairs = (p.a.count + 1) / 2;
     constexpr int NL = (B + T - 1) / T;
@@ -259,6 +270,12 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
             const int k = tid + T * it;
             if (k <= A / 2) ds[k] = wv[it];
         }
+        if constexpr (DEEMPH) {                                 // MFM: taps and both members' carried state ride along
+            if (tid < 51) ds[kScratch + tid] = p.a.deemph_taps[tid];
+            if (tid >= 192 && tid < 192 + 51) ds[kScratch + 12 + tid] = p.a.deemph_taps[51 + tid - 192];   // sfx -> [204, 255)
+            if (tid >= 64 && tid < 64 + 50) ds[kScratch + tid] = p.a.deemph_state[(int64_t)c0 * 50 + (tid - 64)];
+            if (tid >= 128 && tid < 128 + 50) ds[kScratch + tid] = p.a.deemph_state[(int64_t)c1 * 50 + (tid - 128)];
+        }
     }
     lds_barrier();
     RCFM_TRACE_POINT(13);
@@ -296,6 +313,12 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
                         p.a.dc[c0] = make_float2(val.x, 0.f);
                         if (has1) p.a.dc[c1] = make_float2(val.y, 0.f);
                     }
+                    if constexpr (DEEMPH) {
+                        if (k == 0) {                            // ... kept on chip for the mean of the filter output
+                            ds[kScratch + 200] = val.x;
+                            ds[kScratch + 201] = val.y;
+                        }
+                    }
                 }
             }
         }
@@ -325,14 +348,121 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         lds_barrier();
         if (tid < A / Q2) {
 #pragma unroll
-            for (int q = 0; q < Q2; ++q) xs[kb + (A / Q2) * q] = y[dft_slot<Q2>(q)];    // natural order, swapped
+            for (int q = 0; q < Q2; ++q) xs[aswz(kb + (A / Q2) * q)] = y[dft_slot<Q2>(q)];    // natural order, swapped
         }
     }
     lds_barrier();
     RCFM_TRACE_POINT(20);
     float* out0 = p.a.audio + (int64_t)c0 * A;
     float* out1 = p.a.audio + (int64_t)c1 * A;
-    if constexpr (A % 4 == 0) {
+    if constexpr (DEEMPH) {
+        // ---- MFM (mfm.py:62-66): y = lfilter(b, v, zi), y -= mean(y), clip -- both members at once (xs[n] = (v1, v0)) ------
+        // b[0] = 0 and b[j] = c x^(j-1): a truncated geometric series obeys y[n] = x y[n-1] + b[1] v[n-1] - x b[50] v[n-51]
+        // (kernels.hip, k_fir51), a stable recursion (|x| < 1): a lane's run of 32 outputs is one 50-tap sum and 31
+        // three-term steps -- 5 LDS reads per output instead of 100.  The first 56 outputs still see the carried state
+        // (zi[n], n < 50) or would need inputs of the previous buffer: one plain sum each (wave 1).
+        // The mean of y follows from sums that are already here (k_fir51): sum_n y[n] = (sum b) A dc + sum_{i<50}
+        // (zi[i] - v[A-1-i] sum_{j>i} b[j]), dc = the DC bin of v -- so every output is finished and stored as it appears.
+        const float* tp = ds + kScratch;
+        constexpr int PERD = 32, HEAD = 56;
+        static_assert(A > HEAD + PERD, "audio shorter than the filter");
+        constexpr int NRUN = (A - HEAD + PERD - 1) / PERD, NR = (NRUN + T - 1) / T;
+        float2 term = make_float2(0.f, 0.f), hacc = make_float2(0.f, 0.f);
+        if (tid < 50) {
+            // wave 0: this thread's share of the mean, and element `tid` of the NEXT buffer's carried state (k_fir_state):
+            // zf[s] = sum_i b[s + 1 + i] v[A - 1 - i].  (Fixed trip counts with a predicate: the LDS reads pipeline.)
+            const float2 vl = xs[aswz(A - 1 - tid)];
+            const float sf = ds[kScratch + 204 + tid];
+            term = make_float2(ds[kScratch + 128 + tid] - vl.x * sf, ds[kScratch + 64 + tid] - vl.y * sf);
+            float2 zf = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 50; ++i) {
+                const float2 vv = xs[aswz(A - 1 - i)];
+                const float bj = (i < 50 - tid) ? tp[tid + 1 + i] : 0.f;
+                zf = make_float2(fmaf(bj, vv.x, zf.x), fmaf(bj, vv.y, zf.y));
+            }
+            p.a.deemph_state[(int64_t)c0 * 50 + tid] = zf.y;
+            if (has1) p.a.deemph_state[(int64_t)c1 * 50 + tid] = zf.x;
+        } else if (tid >= 64 && tid < 64 + HEAD) {
+            // wave 1: the head -- outputs that still see the carried state, one plain sum each (finished after the barrier)
+            const int n = tid - 64;
+            hacc = n < 50 ? make_float2(ds[kScratch + 128 + n], ds[kScratch + 64 + n]) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 1; j <= 50; ++j) {
+                const float2 vv = xs[aswz(j <= n ? n - j : 0)];
+                const float bj = j <= n ? tp[j] : 0.f;
+                hacc = make_float2(fmaf(bj, vv.x, hacc.x), fmaf(bj, vv.y, hacc.y));
+            }
+        }
+        if (tid < 64) {
+            for (int off = 32; off > 0; off >>= 1) {
+                term.x += __shfl_down(term.x, off, 64);
+                term.y += __shfl_down(term.y, off, 64);
+            }
+            if (tid == 0) {
+                const float bsum = ds[kScratch + 204];           // sfx[0] = sum_{j >= 1} b[j] (b[0] = 0)
+                const float inv = 1.0f / (float)A;
+                ds[kScratch + 192] = fmaf(term.x, inv, bsum * ds[kScratch + 201]);   // member 1 (dc in .y of the swapped pair)
+                ds[kScratch + 193] = fmaf(term.y, inv, bsum * ds[kScratch + 200]);   // member 0
+            }
+        }
+        lds_barrier();
+        const float2 mean = make_float2(ds[kScratch + 192], ds[kScratch + 193]);
+        const float b1 = tp[1], bx = tp[2] / tp[1], xb50 = bx * tp[50];
+        auto fin = [](float y, float m) -> float {
+            const float t = y - m;
+            return (t < -0.999f) ? -0.999f : ((t > 0.999f) ? 0.999f : t);   // NaN stays NaN like np.clip
+        };
+        if (tid >= 64 && tid < 64 + HEAD) {
+            out0[tid - 64] = fin(hacc.y, mean.y);
+            if (has1) out1[tid - 64] = fin(hacc.x, mean.x);
+        }
+#pragma unroll 1
+        for (int r = 0; r < NR; ++r) {
+            const int run = tid + T * r;
+            const int n0 = HEAD + PERD * run;
+            if (run < NRUN) {
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll 10
+                for (int j = 1; j <= 50; ++j) {
+                    const float2 vv = xs[aswz(n0 - j)];
+                    const float bj = tp[j];
+                    acc = make_float2(fmaf(bj, vv.x, acc.x), fmaf(bj, vv.y, acc.y));
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < PERD / 4; ++g4) {
+                    float2 q4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (g4 > 0 || e > 0) {
+                            int n = n0 + 4 * g4 + e;
+                            n = n < A ? n : A - 1;                // (a ragged last run repeats its last sample: not stored)
+                            const float2 va = xs[aswz(n - 1)], vb = xs[aswz(n - 51)];
+                            acc = make_float2(fmaf(bx, acc.x, fmaf(b1, va.x, -xb50 * vb.x)),
+                                              fmaf(bx, acc.y, fmaf(b1, va.y, -xb50 * vb.y)));
+                        }
+                        q4[e] = acc;
+                    }
+                    const int n4 = n0 + 4 * g4;
+                    if ((A % 4 == 0) && n4 + 4 <= A) {
+                        *reinterpret_cast<float4*>(out0 + n4) =
+                            make_float4(fin(q4[0].y, mean.y), fin(q4[1].y, mean.y), fin(q4[2].y, mean.y), fin(q4[3].y, mean.y));
+                        if (has1)
+                            *reinterpret_cast<float4*>(out1 + n4) =
+                                make_float4(fin(q4[0].x, mean.x), fin(q4[1].x, mean.x), fin(q4[2].x, mean.x), fin(q4[3].x, mean.x));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n4 + e < A) {
+                                out0[n4 + e] = fin(q4[e].y, mean.y);
+                                if (has1) out1[n4 + e] = fin(q4[e].x, mean.x);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    } else if constexpr (A % 4 == 0) {
         for (int i = tid; i < A / 4; i += T) {
             const float2 s0 = xs[4 * i], s1 = xs[4 * i + 1], s2 = xs[4 * i + 2], s3 = xs[4 * i + 3];
             reinterpret_cast<float4*>(out0)[i] = make_float4(s0.y, s1.y, s2.y, s3.y);
@@ -411,6 +541,16 @@ bool lds_chain_supported(int B, int A) {
     return false;
 }
 
+// The 640-thread instantiations are capped at 168 VGPRs and spill ~190 dwords with the de-emphasis inside: those
+// geometries keep the de-emphasis launches.
+bool lds_chain_deemph_supported(int B, int A) {
+#define RCFM_CASE(B_, R0, R1, R2, A_, Q0, Q1, Q2, T_) \
+    if (B == B_ && A == A_) return (T_) <= 512;
+    RCFM_LDS_CHAINS(RCFM_CASE)
+#undef RCFM_CASE
+    return false;
+}
+
 bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream) {
     if (args.count <= 0) return true;
     if (!lds_chain_supported(B, A)) return false;
@@ -434,12 +574,20 @@ bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream
     // bins are fetched under the current pair's last transform)
     const unsigned pairs = (unsigned)((args.count + 1) / 2);
     const dim3 grid(std::min<unsigned>(pairs, (unsigned)FftEngine::compute_units()));
-#define RCFM_CASE(B_, R0, R1, R2, A_, Q0, Q1, Q2, T_)                                                        \
-    if (B == B_ && A == A_) {                                                                                \
-        hipLaunchKernelGGL((k_fm_lds<B_, R0, R1, R2, A_, Q0, Q1, Q2, T_>), grid, dim3(T_), 0, stream, p);   \
-        RC_HIP(hipGetLastError());                                                                           \
-        trace_report(p, stream);                                                                             \
-        return true;                                                                                         \
+    const bool deemph = args.deemph_taps != nullptr;
+    RC_REQUIRE(!deemph || (args.deemph_state != nullptr && lds_chain_deemph_supported(B, A)), RCFM_ERR_ARG,
+               "de-emphasis on chip: no carried state, or a geometry without that form");
+#define RCFM_CASE(B_, R0, R1, R2, A_, Q0, Q1, Q2, T_)                                                              \
+    if (B == B_ && A == A_) {                                                                                      \
+        if constexpr ((T_) <= 512) {                                                                               \
+            if (deemph)                                                                                            \
+                hipLaunchKernelGGL((k_fm_lds<B_, R0, R1, R2, A_, Q0, Q1, Q2, T_, true>), grid, dim3(T_), 0, stream, p); \
+        }                                                                                                          \
+        if (!deemph)                                                                                               \
+            hipLaunchKernelGGL((k_fm_lds<B_, R0, R1, R2, A_, Q0, Q1, Q2, T_, false>), grid, dim3(T_), 0, stream, p); \
+        RC_HIP(hipGetLastError());                                                                                 \
+        trace_report(p, stream);                                                                                   \
+        return true;                                                                                               \
     }
     RCFM_LDS_CHAINS(RCFM_CASE)
 #undef RCFM_CASE
