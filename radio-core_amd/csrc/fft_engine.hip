@@ -353,6 +353,14 @@ FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch) const
     return d;
 }
 
+static bool ping_pong_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("RCFM_FFT_PINGPONG");   // =0: middle passes in place (A/B runs)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
                     hipStream_t stream, const FftRowWindow* keep) const {
     if (batch <= 0) return;
@@ -360,9 +368,22 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
     const int64_t n = desc_.n;
     using namespace fftk;
     const int64_t ts = desc_.tmp_stride;
+    // Plans of three and four passes on arrays that cannot stay in the 256 MiB Infinity Cache: no pass runs in place.  The
+    // intermediate arrays alternate between `tmp` and the caller's `out` (a strided pass keeps the layout, and for np >= 3
+    // the scratch rows are not padded: ts == n), ending in tmp -> out.  A tile copy that writes where it reads streams
+    // 1.5 - 4 % slower than one whose output lies elsewhere (tools/microbench/dst_offset.hip, profiles/r04_h_dst_offset.md);
+    // same-box alternation: cfg4 7.252 -> 7.224 ms (the middle pass of N = 2.4e8), cfg5 1.542 -> 1.534 ms.  Cache-resident
+    // transforms keep the in-place middle passes: N = 1e7 (80 MB) lost 3.6 % with twice the footprint.  When out aliases
+    // in or tmp the old routing stays.
+    const bool ping_pong = np >= 3 && ts == n && in != out && out != tmp && in != tmp &&
+                           (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20) && ping_pong_enabled();
+    auto mid = [&](int t) -> float2* {   // where pass t < np - 1 writes
+        if (!ping_pong) return tmp;
+        return ((np - 2 - t) & 1) ? out : tmp;
+    };
     for (int t = 0; t < np; ++t) {
         const bool first = (t == 0), last = (t == np - 1);
-        const float2* src = first ? in : tmp;
+        const float2* src = first ? in : mid(t - 1);
         const FftPassDev dev = pass_dev(t, first ? n : ts, last ? n : ts);
         if (last) {
             LoadPlainT<false> ld{src};
@@ -376,7 +397,7 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
             else
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<false>{out, scale}, stream);
         } else {
-            StorePlainT<false> st{tmp, 1.0f};
+            StorePlainT<false> st{mid(t), 1.0f};
             if (first && inverse)
                 launch_fft_pass<kStridedOnly>(dev, batch, LoadPlainT<true>{src}, st, stream);
             else
