@@ -267,6 +267,53 @@ def stage_roofline(lib, step, N, B, A, kind, channels):
             "algorithmic_bytes_per_launch": alg, "share_of_step": round(ms / total, 3) if total else 0.0}
 
 
+def measure_lanes(lib, hip, x, rolls, bws, N, C, B, A, kind, steps, warmup, one_lane_s, lanes=2):
+    """`pipelined` block: the same K steps with consecutive buffers on `lanes` alternating streams, one handle set per
+    stream, the demodulators sharing ONE de-emphasis state ordered across streams by RCFM_OPT_STATE_FENCE (what
+    radiocore.tools.Lanes does through the class surface; tests/test_hip_lanes.py: bit-identical audio).  Never `value`:
+    the headline stays one buffer at a time, whose kernel durations the roofline block can be read against."""
+    ch = 2 if kind == "WBFM" else 1
+    kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
+    sets = []
+    for k in range(lanes):
+        tuner, demod = ctypes.c_void_p(), ctypes.c_void_p()
+        hip.check(lib.rcfm_tuner_create(N, C, rolls, bws, ctypes.byref(tuner)))
+        hip.check(lib.rcfm_tuner_shard(tuner, 0, C))
+        hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, 0, ctypes.byref(demod)))
+        if k:
+            hip.check(lib.rcfm_demod_bind_state(demod, sets[0][1], 0, 0, hip.stream()))
+        sets.append((tuner, demod, torch.empty((C, A, ch), dtype=torch.float32, device="cuda"), torch.cuda.Stream()))
+    hip.check(lib.rcfm_demod_set_option(sets[0][1], 5, 1))     # RCFM_OPT_STATE_FENCE, after the bindings
+    torch.cuda.synchronize()
+
+    def step(i):
+        tuner, demod, audio, st = sets[i % lanes]
+        s = ctypes.c_void_p(st.cuda_stream)
+        hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
+        hip.check(lib.rcfm_pipeline_run(tuner, demod, 0, C, hip.ptr(audio), s))
+
+    for i in range(warmup + lanes):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    finite = all(bool(torch.isfinite(a).all()) for _, _, a, _ in sets)
+    for tuner, demod, _, _ in sets:
+        hip.check(lib.rcfm_demod_destroy(demod))
+        hip.check(lib.rcfm_tuner_destroy(tuner))
+    del sets
+    torch.cuda.empty_cache()
+    alg = path_bytes(N, C, B, A, kind)
+    return {"lanes": lanes, "ms_per_step": round(dt * 1e3, 4), "value": round(N / dt / 1e6, 1), "unit": "Msamples/s",
+            "steps": steps, "path_hbm_frac": round(alg / dt / HBM_PEAK, 4), "vs_one_lane": round(dt / one_lane_s, 4),
+            "output_finite": finite,
+            "note": "consecutive buffers on alternating streams (radiocore.tools.Lanes / RCFM_OPT_STATE_FENCE); "
+                    "parity: tests/test_hip_lanes.py"}
+
+
 def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
     """One extra configuration on this GPU (cfg3 / cfg5; cfg4 is the headline): K timed steps of
     rcfm_tuner_load + rcfm_pipeline_run, input resident in HBM, same accounting as the headline."""
@@ -299,6 +346,7 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
     hip.check(lib.rcfm_tuner_destroy(tuner))
     del audio
     torch.cuda.empty_cache()
+    pipelined = measure_lanes(lib, hip, x, rolls, bws, N, C, B, A, kind, steps, warmup, dt)
     surface = measure_surface(name, x, centres, steps, warmup, dt) if with_surface else None
     del x
     torch.cuda.empty_cache()
@@ -310,6 +358,7 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
         "path_algorithmic_GB": round(alg / 1e9, 3), "path_hbm_frac": round(alg / dt / HBM_PEAK, 4),
         "path_hbm_frac_read": round(path_read_bytes(N, C, B, A, kind) / dt / HBM_PEAK, 4),
         "roofline": roof,
+        "pipelined": pipelined,
         "output_finite": finite,
         "parity": ("tests/test_hip_configs.py::test_%s_full_size_%s" % (name, kind.lower()) if name.startswith("cfg") else
                    "tests/test_hip_configs.py::test_run_all_narrowband_fm_geometry[MFM-12500-8000-0] (reduced band)" if name == "nbmfm" else
@@ -818,6 +867,8 @@ def main():
     hip.check(lib.rcfm_tuner_destroy(tuner))
     if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras and not multi:
         # the other GPU configurations of BASELINE.json on the same box, outside the headline's timed region
+        result["pipelined"] = measure_lanes(lib, hip, x, roll_a, bw_a, N, C, B, A, kind, args.steps, args.warmup,
+                                            ms_per_step * 1e-3)
         surface4 = measure_surface("cfg4", x, centres, args.steps, args.warmup, ms_per_step * 1e-3)
         del x, audios, audio
         torch.cuda.empty_cache()

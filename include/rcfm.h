@@ -152,8 +152,16 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *                         tuner.py:161 returns them)
  *   RCFM_OPT_NARROW_TILES the tile kernels exist with 16 and with 8 lines per tile: 0 = always 16, 1 (default) = 8 when a
  *                         launch has fewer than two 16-line tiles per CU (one WBFM.run per call, the reference's harness
- *                         shape tests/benchmark.py:29-31: 60 short tiles instead of 30 long ones), 2 = always 8 */
-enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4 };
+ *                         shape tests/benchmark.py:29-31: 60 short tiles instead of 30 long ones), 2 = always 8
+ *   RCFM_OPT_STATE_FENCE  (default 0) consecutive buffers on DIFFERENT streams: the reference's loop
+ *                         (examples/multi_fm_server.py:98-106) handles one buffer at a time; a host that keeps two handle
+ *                         sets (tuner + demodulator, the second demodulator bound to the first one's state with
+ *                         rcfm_demod_bind_state) and alternates them, each on its own stream, lets the kernels of buffer
+ *                         i + 1 fill the gaps of buffer i.  The de-emphasis state is the one thing buffer i + 1 needs
+ *                         from buffer i (deemphasis.py:64): with the fence on, every launch sequence that touches the
+ *                         shared state waits for the event the previous one recorded, on whichever stream that was.
+ *                         Set it on any ONE handle of the sharing group, after the binding */
+enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 

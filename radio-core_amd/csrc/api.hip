@@ -490,7 +490,27 @@ struct rcfm_demod_s {
     // one-channel handle's state IS slot `index` of a batched handle's buffer (shared ownership), so the
     // per-channel caller and the batched caller carry ONE state per channel like the reference's
     // Deemphasis._state (deemphasis.py:48-49,64).
-    std::shared_ptr<DeviceBuffer> state_buf = std::make_shared<DeviceBuffer>();
+    // RCFM_OPT_STATE_FENCE: handles that share one state buffer may run consecutive buffers on DIFFERENT streams (one
+    // handle set per stream, radiocore.tools.Lanes): every launch sequence that reads or writes the state then waits
+    // for the event the previous one recorded.  The fence travels with the buffer (bind_state shares both).
+    struct StateBuf : DeviceBuffer {
+        hipEvent_t ev = nullptr;
+        bool armed = false, recorded = false;
+        ~StateBuf() {
+            if (ev) (void)hipEventDestroy(ev);
+        }
+    };
+    std::shared_ptr<StateBuf> state_buf = std::make_shared<StateBuf>();
+    struct StateFence {   // scope of the launches that touch the state on stream s
+        StateBuf& b;
+        hipStream_t s;
+        StateFence(rcfm_demod_s& d, hipStream_t st) : b(*d.state_buf), s(st) {
+            if (b.armed && b.recorded) RC_HIP(hipStreamWaitEvent(s, b.ev, 0));
+        }
+        ~StateFence() {
+            if (b.armed && hipEventRecord(b.ev, s) == hipSuccess) b.recorded = true;
+        }
+    };
     size_t state_off = 0;   // floats into state_buf
     float* state_ptr() const { return state_buf->as<float>() + state_off; }
     float side_tap = 0.23f;
@@ -640,6 +660,7 @@ struct rcfm_demod_s {
     void run_deemph(const float* v, float* audio, float* st, int cnt, hipStream_t s, bool have_dc = false,
                     int row = 0, int pitch = 0) {
         const bool fast = ((int64_t)A * ch) % 4 == 0;
+        StateFence fence(*this, s);
         if (fast && have_dc && A >= 50) {
             // de-emphasis, DC removal and clip in one kernel: the mean comes from the DC bin (buf_dc)
             {
@@ -803,6 +824,7 @@ struct rcfm_demod_s {
             }
             // wbfm.py:90-100  de-emphasis (separate L/R state), joint DC removal, clip
             float* st = state_ptr() + (size_t)first * ch * 50;
+            StateFence fence(*this, s);
             {
                 StageTimer tm(ST_DEEMPH, s);
                 launch_fir(reinterpret_cast<float*>(V), audio, A, 2, cnt, taps.as<float>(), 51, st,
@@ -898,6 +920,7 @@ struct rcfm_demod_s {
         }
         // mfm.py:63-65
         float* st = state_ptr() + (size_t)first * 50;
+        StateFence fence(*this, s);
         {
             StageTimer tm(ST_DEEMPH, s);
             launch_fir(v, audio, A, 1, cnt, taps.as<float>(), 51, st, partial.as<float>(), s);
@@ -1329,6 +1352,13 @@ int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
                 RC_REQUIRE(value >= 0 && value <= 2, RCFM_ERR_ARG, "narrow tiles: 0 never, 1 automatic, 2 always");
                 d->opt_narrow = value;
                 break;
+            case RCFM_OPT_STATE_FENCE: {
+                auto& b = *d->state_buf;
+                if (value != 0 && b.ev == nullptr) RC_HIP(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+                b.armed = value != 0;
+                if (!b.armed) b.recorded = false;
+                break;
+            }
             default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown demodulator option");
         }
     });
@@ -1386,6 +1416,8 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                     a.dc = nullptr;
                 }
                 {
+                    std::unique_ptr<rcfm_demod_s::StateFence> fence;   // the on-chip de-emphasis reads and writes the state
+                    if (deemph_on_chip) fence = std::make_unique<rcfm_demod_s::StateFence>(*d, as_stream(stream));
                     StageTimer tm(ST_LDS_CHAIN, as_stream(stream));
                     RC_REQUIRE(launch_lds_chain(d->B, d->A, a, as_stream(stream)), RCFM_ERR_RUNTIME,
                                "LDS chain refused a geometry it lists");

@@ -8,3 +8,4 @@ from radiocore.tools.ringbuffer import *
 from radiocore.tools.sharding import *
 from radiocore.tools.wire import *
 from radiocore.tools.feeder import *
+from radiocore.tools.lanes import *

@@ -1,0 +1,78 @@
+"""Lanes: consecutive wideband buffers on alternating HIP streams (no reference counterpart).
+
+The reference's server handles one buffer at a time (examples/multi_fm_server.py:98-106: ``load``, then every channel's
+``run`` -> ``demodulator.run``).  On the GPU every stage of that loop is a launch whose last workgroups leave part of the
+chip idle, and the wideband FFT of buffer i + 1 does not depend on anything buffer i computes: with two handle sets
+(spectrum + workspaces each), each on its own stream, the kernels of the next buffer fill the gaps of the current one.
+The ONE thing buffer i + 1 needs from buffer i is the de-emphasis state (deemphasis.py:64; mfm.py:63, wbfm.py:97-100):
+the lanes share it, and librcfm orders the launches that touch it across streams (RCFM_OPT_STATE_FENCE), so the audio is
+bit-identical to the one-buffer-at-a-time loop.
+
+Measured (profiles/r04_i_lanes.md, same-box alternations): cfg4 -2.6 %, cfg5 -1 %, cfg3 (64 channels, launches of a few
+tiles per CU) -14 %.  Costs one more spectrum and workspace set per lane (cfg4: 14 GB).
+"""
+
+from radiocore._internal import hip
+from radiocore.tools.tuner import Tuner
+
+__all__ = ["Lanes"]
+
+
+class Lanes:
+    """``depth`` buffers in flight through one Tuner's channels.
+
+        lanes = Lanes(tuner, depth=2)
+        t0 = lanes.submit(buffer0)          # returns at once; load + run_all are queued on lane 0's stream
+        t1 = lanes.submit(buffer1)          # lane 1: overlaps buffer0's kernels
+        audio0 = lanes.result(t0)           # [C, A, ch] like Tuner.run_all(); waits for that buffer only
+
+    Buffers are demodulated in submission order as far as the per-channel state is concerned; results may be collected
+    in any order, each once.  ``tuner`` stays usable on its own between submissions (it is lane 0).
+    """
+
+    def __init__(self, tuner: Tuner, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self._torch = hip.torch()
+        self._base = tuner
+        tuner._arm_state_fence()
+        self._tuners = [tuner] + [tuner._lane_clone() for _ in range(depth - 1)]
+        self._streams = [self._torch.cuda.Stream() for _ in range(depth)]
+        self._next = 0
+        self._pending = {}          # ticket -> (event, audio tensor)
+
+    @property
+    def depth(self) -> int:
+        return len(self._tuners)
+
+    def submit(self, input_signal, chunk: int = 0) -> int:
+        """Queue Tuner.load + Tuner.run_all of one buffer on the next lane; returns a ticket for ``result``."""
+        ticket = self._next
+        self._next += 1
+        k = ticket % len(self._tuners)
+        t = self._tuners[k]
+        if k:
+            t._sync_lane(self._base)            # channels added since the lane was made
+        st = self._streams[k]
+        st.wait_stream(self._torch.cuda.current_stream())     # whatever produced the buffer
+        with self._torch.cuda.stream(st):
+            t.load(input_signal)
+            audio = t._run_all_device(chunk)
+            ev = st.record_event()
+        self._pending[ticket] = (ev, audio)
+        return ticket
+
+    def result(self, ticket: int, numpy_output: bool = True):
+        """The audio of one submitted buffer, [C, A, ch] float32 (the shard's block after Tuner.shard)."""
+        ev, audio = self._pending.pop(ticket)
+        if numpy_output or not self._base._cuda:
+            ev.synchronize()
+            return hip.to_host(audio)
+        self._torch.cuda.current_stream().wait_event(ev)      # stream-ordered hand-over, no host wait
+        audio.record_stream(self._torch.cuda.current_stream())
+        return audio
+
+    def drain(self):
+        """Wait for everything submitted so far (results stay collectable)."""
+        for ev, _ in self._pending.values():
+            ev.synchronize()

@@ -63,6 +63,7 @@ class Tuner(Injector):
         self._uniform = (None, None)   # (version, the one geometry all channels share or None)
         self._state_owner = {}     # (kind, C, B, A, tau) -> the batched handle whose buffer holds that geometry's state
         self._bound_version = {}   # batched key -> channel-list version its demodulators were bound at
+        self._state_fence = False  # Lanes: this tuner's batched handles run on several streams (RCFM_OPT_STATE_FENCE)
 
     @property
     def input_frequency(self) -> float:
@@ -281,6 +282,10 @@ class Tuner(Injector):
         After ``shard(first, count)`` only that range is run (its spectrum rows are all ``load``
         kept) and the result is [count, A, ch] -- the block sharding.gather_audio expects.
         """
+        return self._result(self._run_all_device(chunk), self._cuda and not numpy_output)
+
+    def _run_all_device(self, chunk=0):
+        # run_all's launches on the current stream; the device tensor they fill (Lanes collects it later)
         handle = self._ready()
         _, first, count = self._launch_plan()
         geo = self._plan_uniform()     # ALL channels of the tuner, not only the shard's
@@ -291,7 +296,7 @@ class Tuner(Injector):
         audio = hip.empty((count, A, ch), self._torch.float32)
         hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, chunk), first, count,
                                               hip.ptr(audio), hip.stream()))
-        return self._result(audio, self._cuda and not numpy_output)
+        return audio
 
     def _plan_uniform(self):
         """(kind, B, A, tau) when every channel of the tuner carries the same demodulator class and geometry,
@@ -356,6 +361,8 @@ class Tuner(Injector):
             if opts[3] != 1:
                 hip.check(self._lib.rcfm_demod_set_option(h, hip.RCFM_OPT_NARROW_TILES, opts[3]))
             self._bind_states(key, self._batched[key])
+            if self._state_fence and kind != hip.RCFM_FM:    # after the binding: the fence travels with the state buffer
+                hip.check(self._lib.rcfm_demod_set_option(h, hip.RCFM_OPT_STATE_FENCE, 1))
         elif self._bound_version.get(key) != self._version:
             self._bind_states(key, self._batched[key])
         return self._batched[key].value
@@ -378,6 +385,8 @@ class Tuner(Injector):
             self._state_owner[owner_key] = handle
         elif owner.value != handle.value:
             hip.check(self._lib.rcfm_demod_bind_state(handle.value, owner.value, 0, 0, hip.stream()))   # the owner has the history
+        if getattr(self, "_is_lane", False):
+            return                            # the channels' demodulator objects stay bound to the base tuner's handle
         geo = (kind, B, A, tau)
         seen = set()
         for c in self._bounds:
@@ -386,3 +395,37 @@ class Tuner(Injector):
                 continue                      # (an object registered on two channels keeps its first slot)
             seen.add(id(d))
             d._bind(handle, c.index)
+
+    # ---- consecutive buffers on several streams (radiocore.tools.Lanes) ---------------------------------------------
+
+    def _arm_state_fence(self):
+        """From now on this tuner's batched demodulator handles may be used from several streams: every launch sequence
+        that touches the shared de-emphasis state waits for the previous one (rcfm_demod_set_option, RCFM_OPT_STATE_FENCE)."""
+        self._state_fence = True
+        for key, h in self._batched.items():
+            if key[0] != hip.RCFM_FM:
+                hip.check(self._lib.rcfm_demod_set_option(h.value, hip.RCFM_OPT_STATE_FENCE, 1))
+
+    def _lane_clone(self):
+        """A second Tuner over the SAME channel list, demodulator objects and de-emphasis state, with its own device
+        handles (spectrum, workspaces): what one more stream needs to work on the next buffer."""
+        t = Tuner(cuda=self._cuda)
+        t._is_lane = True
+        t._sync_lane(self)
+        return t
+
+    def _sync_lane(self, base):
+        if self._version == base._version and self._bounds is base._bounds and self._shard == base._shard and \
+                self._input_bandwidth == base._input_bandwidth:
+            return
+        self._bounds = base._bounds
+        self._input_frequency, self._input_bandwidth = base._input_frequency, base._input_bandwidth
+        self._lo, self._hi, self._bw_sum = base._lo, base._hi, base._bw_sum
+        self._version = base._version
+        self._win_size = base._win_size
+        self._state_owner = base._state_owner          # one state per channel, whoever runs it
+        self._state_fence = True
+        if hasattr(base, "_kernel_options"):
+            self._kernel_options = base._kernel_options
+        if base._shard is not None and self._shard != base._shard:
+            self.shard(*base._shard)
