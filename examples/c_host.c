@@ -4,7 +4,8 @@
  * Tuner.run -> WBFM.run, publish) in C: page-locked ring of input buffers -> rcfm_feeder (H2D copy of buffer i+1 under
  * the kernels of buffer i) -> rcfm_tuner_load -> rcfm_pipeline_run -> rcfm_gather_audio on a one-rank communicator ->
  * host.  Writes the input buffers and the audio to files so that tests/test_c_host.py can check them against the
- * oracle.
+ * oracle; then the same buffers through the rotating FFT owner's protocol and through two lanes (two streams), both
+ * required to reproduce that audio bit for bit.
  *
  *   gcc -O2 -Iinclude examples/c_host.c -Lradio-core_amd/radiocore/_lib -lrcfm -lm \
  *       -Wl,-rpath,$PWD/radio-core_amd/radiocore/_lib -o examples/c_host
@@ -184,6 +185,59 @@ int main(int argc, char** argv) {
         CHECK(rcfm_free(own));
         CHECK(rcfm_free(mine));
         CHECK(rcfm_free(xdev));
+    }
+    /* ---- the same buffers through TWO LANES: consecutive buffers on alternating streams ---------------------------------
+     * (rcfm.h, RCFM_OPT_STATE_FENCE).  One handle set per lane -- tuner (spectrum + scratch), demodulator (workspaces),
+     * device input and output -- and ONE de-emphasis state: lane 1's demodulator is bound to lane 0's, and the fence orders
+     * the launches that touch the state across the two streams.  Nothing is waited for until all buffers are queued; the
+     * audio must equal the file written by the one-buffer-at-a-time loop above, bit for bit. */
+    {
+        enum { LANES = 2 };
+        rcfm_tuner_t ltuner[LANES];
+        rcfm_demod_t ldemod[LANES];
+        void *lstream[LANES], *lx[LANES], *lout[BUFFERS];
+        for (int k = 0; k < LANES; ++k) {
+            CHECK(rcfm_tuner_create(N, C, roll, bw, &ltuner[k]));
+            CHECK(rcfm_tuner_shard(ltuner[k], 0, C));
+            CHECK(rcfm_demod_create(RCFM_WBFM, C, B, A, 75e-6, 0, &ldemod[k]));
+            if (k) CHECK(rcfm_demod_bind_state(ldemod[k], ldemod[0], 0, 0, NULL));
+            CHECK(rcfm_stream_create(&lstream[k]));
+            CHECK(rcfm_malloc(&lx[k], sizeof(float) * 2 * N));
+        }
+        CHECK(rcfm_demod_set_option(ldemod[0], RCFM_OPT_STATE_FENCE, 1));     /* after the binding */
+        CHECK(rcfm_stream_sync(NULL));
+        for (int b = 0; b < BUFFERS; ++b) {
+            const int k = b % LANES;
+            CHECK(rcfm_malloc(&lout[b], sizeof(float) * C * A * 2));
+            /* stream-ordered on lane k: its previous buffer's kernels have read lx[k] before this copy overwrites it */
+            CHECK(rcfm_memcpy_h2d(lx[k], ring + (size_t)b * 2 * N, sizeof(float) * 2 * N, lstream[k]));
+            CHECK(rcfm_tuner_load(ltuner[k], lx[k], lstream[k]));
+            CHECK(rcfm_pipeline_run(ltuner[k], ldemod[k], 0, C, lout[b], lstream[k]));
+        }
+        for (int k = 0; k < LANES; ++k) CHECK(rcfm_stream_sync(lstream[k]));
+        snprintf(path, sizeof(path), "%s/c_host_audio.bin", dir);
+        f = fopen(path, "rb");
+        float* want = (float*)malloc(sizeof(float) * C * A * 2);
+        if (!f || !want) return 4;
+        for (int b = 0; b < BUFFERS; ++b) {
+            CHECK(rcfm_memcpy_d2h(audio_host, lout[b], sizeof(float) * C * A * 2, NULL));
+            CHECK(rcfm_stream_sync(NULL));
+            if (fread(want, sizeof(float), (size_t)C * A * 2, f) != (size_t)C * A * 2) return 4;
+            if (memcmp(want, audio_host, sizeof(float) * C * A * 2) != 0) {
+                fprintf(stderr, "two lanes: buffer %d differs from the one-buffer-at-a-time loop\n", b);
+                return 7;
+            }
+            printf("two lanes, buffer %d on stream %d: audio identical\n", b, b % LANES);
+            CHECK(rcfm_free(lout[b]));
+        }
+        fclose(f);
+        free(want);
+        for (int k = 0; k < LANES; ++k) {
+            CHECK(rcfm_demod_destroy(ldemod[k]));
+            CHECK(rcfm_tuner_destroy(ltuner[k]));
+            CHECK(rcfm_stream_destroy(lstream[k]));
+            CHECK(rcfm_free(lx[k]));
+        }
     }
     CHECK(rcfm_host_unregister(ring));
     CHECK(rcfm_comm_destroy(comm));

@@ -22,11 +22,13 @@ import numpy as np  # noqa: E402
 
 import workloads  # noqa: E402
 from radiocore import WBFM, Buffer, Feeder, RingBuffer, Tuner  # noqa: E402
+from radiocore.tools import Lanes  # noqa: E402
 from radiocore.tools import wire  # noqa: E402
 
 
-def run(seconds=3, channels=6, rate=1_200_000, bandwidth=60_000, audio_rate=12_000, publish=None):
-    """Returns [(frequency, float32 [A, 2])] per second and channel, in publish order."""
+def run(seconds=3, channels=6, rate=1_200_000, bandwidth=60_000, audio_rate=12_000, publish=None, lanes=1):
+    """Returns [(frequency, float32 [A, 2])] per second and channel, in publish order.  lanes > 1: that many seconds in
+    flight on alternating streams (radiocore.tools.Lanes); a second's messages then leave one submission later."""
     centres = workloads.channel_grid(channels, 50_000)
     tuner = Tuner(cuda=True)
     for f in centres:
@@ -54,6 +56,15 @@ def run(seconds=3, channels=6, rate=1_200_000, bandwidth=60_000, audio_rate=12_0
     t.start()
     pending = 0                                       # seconds submitted to the feeder, not yet processed
     got = 0
+    pipe = Lanes(tuner, depth=lanes) if lanes > 1 else None
+    tickets = []
+
+    def publish_all(audio):
+        for message in wire.frames(tuner.channels(), audio):
+            if publish is not None:
+                publish(message)                      # socket.send_multipart(message) in the reference
+            out.append(wire.parse_frame(message, 2))
+
     while got < seconds:
         while pending < feeder.depth and got + pending < seconds:
             buf = staging[(got + pending) % len(staging)]
@@ -62,14 +73,20 @@ def run(seconds=3, channels=6, rate=1_200_000, bandwidth=60_000, audio_rate=12_0
             feeder.submit(buf.data)                   # its H2D copy starts now, on the copy stream
             pending += 1
         with feeder.next() as x:                      # orders the DSP stream behind this second's copy only
-            tuner.load(x)
-            audio = tuner.run_all()                   # [C, A, 2]: every channel's run -> demodulator.run
+            if pipe is None:
+                tuner.load(x)
+                audio = tuner.run_all()               # [C, A, 2]: every channel's run -> demodulator.run
+            else:
+                tickets.append(pipe.submit(x))        # queued on the next lane's stream; returns at once
+                pipe.hold_current_stream(tickets[-1])   # the feeder frees this slot behind the current stream
         pending -= 1
         got += 1
-        for message in wire.frames(tuner.channels(), audio):
-            if publish is not None:
-                publish(message)                      # socket.send_multipart(message) in the reference
-            out.append(wire.parse_frame(message, 2))
+        if pipe is None:
+            publish_all(audio)
+        elif len(tickets) >= lanes:                   # `lanes` seconds in flight: collect the oldest
+            publish_all(pipe.result(tickets.pop(0)))
+    for tk in tickets:
+        publish_all(pipe.result(tk))
     t.join()
     return out
 
@@ -79,9 +96,10 @@ if __name__ == "__main__":
     ap.add_argument("--seconds", type=int, default=3)
     ap.add_argument("--channels", type=int, default=6)
     ap.add_argument("--rate", type=int, default=1_200_000)
+    ap.add_argument("--lanes", type=int, default=1)
     a = ap.parse_args()
     t0 = time.perf_counter()
-    msgs = run(a.seconds, a.channels, a.rate)
+    msgs = run(a.seconds, a.channels, a.rate, lanes=a.lanes)
     dt = time.perf_counter() - t0
     print("%d messages (%d s x %d channels), %.1f MB of audio, %.2f s wall" %
           (len(msgs), a.seconds, a.channels, sum(m[1].nbytes for m in msgs) / 1e6, dt))

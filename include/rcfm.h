@@ -70,6 +70,11 @@ int rcfm_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream)
 int rcfm_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
 int rcfm_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 int rcfm_stream_sync(void* stream);
+/* A stream of the host's own for hosts without a HIP header (examples/c_host.c runs two lanes, RCFM_OPT_STATE_FENCE below):
+ * hipStreamCreateWithFlags(hipStreamNonBlocking) / hipStreamDestroy.  Every `void* stream` argument of this header takes
+ * one (or any hipStream_t, or NULL for the default stream). */
+int rcfm_stream_create(void** stream);
+int rcfm_stream_destroy(void* stream);
 
 /* ---- Tuner (radiocore/tools/tuner.py) ------------------------------------ */
 

@@ -1082,6 +1082,21 @@ int rcfm_stream_sync(void* stream) {
     return guarded([&] { RC_HIP(hipStreamSynchronize(as_stream(stream))); });
 }
 
+int rcfm_stream_create(void** stream) {
+    return guarded([&] {
+        RC_REQUIRE(stream != nullptr, RCFM_ERR_ARG, "stream is NULL");
+        hipStream_t s = nullptr;
+        RC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *stream = s;
+    });
+}
+
+int rcfm_stream_destroy(void* stream) {
+    return guarded([&] {
+        if (stream) RC_HIP(hipStreamDestroy(as_stream(stream)));
+    });
+}
+
 // ---- tuner -----------------------------------------------------------------
 
 int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_t* bw_host, rcfm_tuner_t* out) {

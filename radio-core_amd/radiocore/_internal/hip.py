@@ -40,6 +40,8 @@ SIGNATURES = {
     "rcfm_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "rcfm_memcpy_d2d": [_vp, _vp, _sz, _vp],
     "rcfm_stream_sync": [_vp],
+    "rcfm_stream_create": [ctypes.POINTER(_vp)],
+    "rcfm_stream_destroy": [_vp],
     "rcfm_tuner_create": [_i64, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp)],
     "rcfm_tuner_load": [_vp, _vp, _vp],
     "rcfm_tuner_shard": [_vp, _i, _i],

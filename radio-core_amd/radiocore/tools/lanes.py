@@ -72,6 +72,12 @@ class Lanes:
         audio.record_stream(self._torch.cuda.current_stream())
         return audio
 
+    def hold_current_stream(self, ticket: int):
+        """Order the CURRENT stream behind one submitted buffer: for a caller that recycles the buffer's storage
+        stream-ordered (``with feeder.next() as x: t = lanes.submit(x); lanes.hold_current_stream(t)`` -- the Feeder
+        frees the slot behind the current stream, which must therefore wait for the lane that still reads it)."""
+        self._torch.cuda.current_stream().wait_event(self._pending[ticket][0])
+
     def drain(self):
         """Wait for everything submitted so far (results stay collectable)."""
         for ev, _ in self._pending.values():

@@ -39,6 +39,8 @@ def test_c_host_output_matches_the_oracle(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([exe, str(tmp_path)], check=True, capture_output=True, text=True, env=env, timeout=600)
     assert out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+    # the rotating owner's hand-over and the two-lane loop (two streams, RCFM_OPT_STATE_FENCE) both reproduced the audio file
+    assert "rotating owner, buffer 2" in out.stdout and "two lanes, buffer 2 on stream 0: audio identical" in out.stdout
     N, C, B, A, K = 600000, 3, 60000, 12000, 3
     x = np.fromfile(str(tmp_path / "c_host_input.bin"), np.float32).view(np.complex64).reshape(K, N)
     audio = np.fromfile(str(tmp_path / "c_host_audio.bin"), np.float32).reshape(K, C, A, 2)

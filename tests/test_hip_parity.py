@@ -483,3 +483,8 @@ def test_server_loop_example(rc, oracle):
             assert freq == int(c.center_frequency)
             want = c.demodulator.run(ref.run_pruned(c.index))[0]
             assert rel_err(pcm, want) <= TOL, (s, c.index)
+    # the same loop with two seconds in flight on alternating streams (radiocore.tools.Lanes): the same messages, bit for bit
+    msgs2 = mod.run(seconds, C, rate, B, A, lanes=2)
+    assert len(msgs2) == len(msgs)
+    for (f1, a1), (f2, a2) in zip(msgs, msgs2):
+        assert f1 == f2 and np.array_equal(a1, a2)
