@@ -8,8 +8,8 @@ The ONE thing buffer i + 1 needs from buffer i is the de-emphasis state (deempha
 the lanes share it, and librcfm orders the launches that touch it across streams (RCFM_OPT_STATE_FENCE), so the audio is
 bit-identical to the one-buffer-at-a-time loop.
 
-Measured (profiles/r04_i_lanes.md, same-box alternations): cfg4 -2.6 %, cfg5 -1 %, cfg3 (64 channels, launches of a few
-tiles per CU) -14 %.  Costs one more spectrum and workspace set per lane (cfg4: 14 GB).
+Measured (`pipelined` blocks of profiles/r04_i_bench.json, same box as the one-lane figure): cfg4 -2 %, cfg5 -2 %, cfg3 (64 channels, launches of a few
+tiles per CU) -11 %.  Costs one more spectrum and workspace set per lane (cfg4: 14 GB).
 """
 
 from radiocore._internal import hip
