@@ -28,6 +28,9 @@ class Lanes:
 
     Buffers are demodulated in submission order as far as the per-channel state is concerned; results may be collected
     in any order, each once.  ``tuner`` stays usable on its own between submissions (it is lane 0).
+    Submit from ONE host thread (or order the calls yourself): the order of the host calls is the order of the buffers,
+    and the fence is armed by whichever call came last.  Before resetting or reading a demodulator's state by hand
+    (``demodulator.reset()``), ``drain()`` first.
     """
 
     def __init__(self, tuner: Tuner, depth: int = 2):
