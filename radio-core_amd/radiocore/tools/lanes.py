@@ -48,8 +48,10 @@ class Lanes:
     def depth(self) -> int:
         return len(self._tuners)
 
-    def submit(self, input_signal, chunk: int = 0) -> int:
-        """Queue Tuner.load + Tuner.run_all of one buffer on the next lane; returns a ticket for ``result``."""
+    def submit(self, input_signal, chunk: int = 0, each: bool = False) -> int:
+        """Queue Tuner.load + Tuner.run_all of one buffer on the next lane; returns a ticket for ``result``.
+        each=True: Tuner.run_each instead (channels of different classes and geometries; ``result`` then returns its
+        list of per-channel arrays)."""
         ticket = self._next
         self._next += 1
         k = ticket % len(self._tuners)
@@ -60,7 +62,7 @@ class Lanes:
         st.wait_stream(self._torch.cuda.current_stream())     # whatever produced the buffer
         with self._torch.cuda.stream(st):
             t.load(input_signal)
-            audio = t._run_all_device(chunk)
+            audio = t._run_each_device() if each else t._run_all_device(chunk)
             ev = st.record_event()
         self._pending[ticket] = (ev, audio)
         return ticket
@@ -68,12 +70,17 @@ class Lanes:
     def result(self, ticket: int, numpy_output: bool = True):
         """The audio of one submitted buffer, [C, A, ch] float32 (the shard's block after Tuner.shard)."""
         ev, audio = self._pending.pop(ticket)
-        if numpy_output or not self._base._cuda:
+        device_output = self._base._cuda and not numpy_output
+        if device_output:
+            cur = self._torch.cuda.current_stream()
+            cur.wait_event(ev)                                 # stream-ordered hand-over, no host wait
+            for a in ([b[2] for b in audio] if isinstance(audio, list) else [audio]):
+                a.record_stream(cur)
+        else:
             ev.synchronize()
-            return hip.to_host(audio)
-        self._torch.cuda.current_stream().wait_event(ev)      # stream-ordered hand-over, no host wait
-        audio.record_stream(self._torch.cuda.current_stream())
-        return audio
+        if isinstance(audio, list):                            # submit(each=True): Tuner.run_each's list
+            return self._base._each_result(audio, device_output)
+        return audio if device_output else hip.to_host(audio)
 
     def hold_current_stream(self, ticket: int):
         """Order the CURRENT stream behind one submitted buffer: for a caller that recycles the buffer's storage

@@ -316,9 +316,13 @@ class Tuner(Injector):
         de-emphasis state is the tuner's, per channel, as in ``run_all``.  After ``shard(first, count)`` the list
         covers that range only.
         """
+        return self._each_result(self._run_each_device(), self._cuda and not numpy_output)
+
+    def _run_each_device(self):
+        # run_each's launches on the current stream; [(n, ch, device tensor [n, A, ch])] per group of like channels
         handle = self._ready()
         groups, first, count = self._launch_plan()
-        out = []
+        blocks = []
         for i, n, kind, B, A, tau in groups:
             if kind is None:
                 raise ValueError("run_each needs an FM, MFM or WBFM demodulator on every channel")
@@ -326,7 +330,13 @@ class Tuner(Injector):
             audio = hip.empty((n, A, ch), self._torch.float32)
             hip.check(self._lib.rcfm_pipeline_run(handle, self._batched_demod(kind, B, A, tau, 0), i, n,
                                                   hip.ptr(audio), hip.stream()))
-            block = self._result(audio, self._cuda and not numpy_output)
+            blocks.append((n, ch, audio))
+        return blocks
+
+    def _each_result(self, blocks, device_output):
+        out = []
+        for n, ch, audio in blocks:
+            block = self._result(audio, device_output)
             out.extend(block[k:k + 1] if ch == 2 else block[k] for k in range(n))
         return out
 

@@ -99,3 +99,44 @@ def test_result_as_device_tensor_and_drain():
     assert torch.isfinite(a0).all() and torch.isfinite(a1).all() and not torch.equal(a0, a1)
     with pytest.raises(KeyError):
         lanes.result(t0)
+
+
+def test_lanes_with_mixed_channel_sets():
+    """submit(each=True): broadcast stations next to narrow-band ones (Tuner.run_each), three geometries, two lanes."""
+    import radiocore as rc
+    from radiocore.tools import Lanes
+
+    def band():
+        tuner = rc.Tuner(cuda=True)
+        spec = [("WBFM", 60000, 12000), ("WBFM", 60000, 12000), ("MFM", 12500, 8000), ("MFM", 12500, 8000),
+                ("MFM", 12500, 8000), ("FM", 25000, 5000)]
+        f = 100e6
+        for kind, B, A in spec:
+            tuner.add_channel(f, B, getattr(rc, kind)(B, A, cuda=True))
+            f += 70000
+        tuner.request_bandwidth(600000.0)
+        return tuner
+
+    rng = np.random.default_rng(3)
+    n = 600000
+    t = np.arange(n) / n
+    bufs = []
+    tuner = band()
+    for b in range(4):
+        x = np.zeros(n, np.complex128)
+        for c, chn in enumerate(tuner.channels()):
+            fc = chn.center_frequency - tuner.input_frequency
+            msg = 0.5 * np.sin(2 * np.pi * (250 + 90 * c + 40 * b) * t)
+            x += np.exp(1j * 2 * np.pi * (fc * t + 0.1 * chn.bandwidth / (2 * np.pi) * np.cumsum(msg) / n))
+        bufs.append((x + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64))
+    want = []
+    for x in bufs:
+        tuner.load(x)
+        want.append(tuner.run_each())
+    lanes = Lanes(band(), depth=2)
+    tickets = [lanes.submit(x, each=True) for x in bufs]
+    for i, tk in enumerate(tickets):
+        got = lanes.result(tk)
+        assert len(got) == len(want[i]) == 6
+        for g, w in zip(got, want[i]):
+            assert g.shape == w.shape and np.array_equal(g, w), i
