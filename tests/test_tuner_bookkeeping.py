@@ -22,6 +22,9 @@ class _FakeTensor:
     def __getitem__(self, k):
         return self
 
+    def record_stream(self, stream):
+        pass
+
 
 class _FakeLib:
     """Every entry point returns 0 and counts its calls; *_create hands out a non-null handle."""
@@ -158,3 +161,99 @@ def test_launch_plan_groups_and_shard(fake_backend):
     assert (first, count) == (2, 3) and [(g[0], g[1]) for g in groups] == [(2, 1), (3, 2)]
     with pytest.raises(IndexError):
         t.shard(5, 4)
+
+
+class _FakeEvent:
+    def synchronize(self):
+        pass
+
+
+class _FakeStream:
+    def __init__(self, log, name):
+        self.log, self.name = log, name
+
+    def wait_stream(self, other):
+        self.log.append(("wait_stream", self.name, other.name))
+
+    def wait_event(self, ev):
+        self.log.append(("wait_event", self.name))
+
+    def record_event(self):
+        self.log.append(("record_event", self.name))
+        return _FakeEvent()
+
+
+def test_lanes_bookkeeping(fake_backend, monkeypatch):
+    """radiocore.tools.Lanes without a device: lane k of `depth` gets buffer i = k (mod depth) on its own stream, every
+    lane has its own tuner and demodulator handle, the extra demodulator handles are bound to the FIRST one's state
+    (one de-emphasis state per channel, whoever runs it) and the fence option is set after the binding; a channel added
+    later reaches every lane."""
+    import contextlib
+    from radiocore._internal import hip
+    from radiocore.tools.lanes import Lanes
+
+    lib = fake_backend
+    log, order = [], []
+    real_getattr = type(lib).__getattr__
+
+    def recording(self, name):
+        fn = real_getattr(self, name)
+
+        def wrapped(*args):
+            order.append((name,) + tuple(a if isinstance(a, int) else getattr(a, "value", None) for a in args[:4]))
+            return fn(*args)
+        return wrapped
+    monkeypatch.setattr(type(lib), "__getattr__", recording)
+
+    current = [_FakeStream(log, "default")]
+
+    class _Cuda:
+        @staticmethod
+        def Stream():
+            log.append(("new",))
+            return _FakeStream(log, "lane%d" % (sum(1 for e in log if e[0] == "new") - 1))
+
+        @staticmethod
+        def current_stream():
+            return current[0]
+
+        @staticmethod
+        @contextlib.contextmanager
+        def stream(st):
+            prev, current[0] = current[0], st
+            log.append(("enter", st.name))
+            try:
+                yield
+            finally:
+                current[0] = prev
+
+    class _Torch(_FakeTorch):
+        cuda = _Cuda
+    monkeypatch.setattr(hip, "torch", lambda: _Torch)
+
+    t = _tuner(6, cls=WBFM)          # WBFM carries state (FM would need no fence)
+    N = 1_000_000
+    t.request_bandwidth(float(N))
+    lanes = Lanes(t, depth=2)
+    x = _FakeTensor((N,))
+    tickets = [lanes.submit(x) for _ in range(5)]
+    assert tickets == [0, 1, 2, 3, 4] and lanes.depth == 2
+    assert lib.calls["rcfm_tuner_create"] == 2 and lib.calls["rcfm_demod_create"] == 2
+    assert lib.calls["rcfm_tuner_load"] == 5 and lib.calls["rcfm_pipeline_run"] == 5
+    assert lib.calls["rcfm_demod_bind_state"] == 1                 # the second lane's handle -> the first one's state
+    names = [o[0] for o in order]
+    bind_at = names.index("rcfm_demod_bind_state")
+    fences = [i for i, o in enumerate(order) if o[0] == "rcfm_demod_set_option" and o[2:4] == (hip.RCFM_OPT_STATE_FENCE, 1)]
+    assert len(fences) == 2 and fences[1] > bind_at                # each lane's handle, the bound one after its binding
+    entered = [e[1] for e in log if e[0] == "enter"]
+    assert entered[0] != entered[1] and entered == [entered[0], entered[1]] * 2 + [entered[0]]
+    assert sum(1 for e in log if e[0] == "wait_stream") == 5      # every lane stream waits for the buffer's producer
+    for tk in reversed(tickets):
+        assert lanes.result(tk, numpy_output=False).shape == (6, 8000, 2)
+    with pytest.raises(KeyError):
+        lanes.result(0)
+    t.add_channel(101e6, 12500, WBFM(12500, 8000))                 # the channel list changes: both lanes rebuild
+    before = lib.calls["rcfm_tuner_create"]
+    for _ in range(2):
+        lanes.result(lanes.submit(x), numpy_output=False)
+    assert lib.calls["rcfm_tuner_create"] == before + 2
