@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K complete handle sets (tuner + demodulator) of one configuration in ONE process, all kept alive: every set's buffers lie
-somewhere else.  The same input through each set, timed per set (whole step and per stage): how much of the "box to box"
+somewhere else (a third argument: each set also gets its own copy of the input).  The same input through each set, timed per set (whole step and per stage): how much of the "box to box"
 spread of the bench is where hipMalloc happened to put the workspaces?"""
 import ctypes
 import os
@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from radiocore._internal import hip  # noqa: E402
 
 
-def main(K=6, config="cfg4"):
+def main(K=6, config="cfg4", clone_input=False):
     lib = hip.lib()
     hip.torch()
     N, C, B, A, raster, kind = bench.CONFIGS[config]
@@ -28,12 +28,12 @@ def main(K=6, config="cfg4"):
         hip.check(lib.rcfm_tuner_create(N, C, rolls, bws, ctypes.byref(t)))
         hip.check(lib.rcfm_tuner_shard(t, 0, C))
         hip.check(lib.rcfm_demod_create({"FM": 0, "MFM": 1, "WBFM": 2}[kind], C, B, A, 75e-6, 0, ctypes.byref(d)))
-        sets.append((t, d, torch.empty((C, A, ch), dtype=torch.float32, device="cuda")))
+        sets.append((t, d, torch.empty((C, A, ch), dtype=torch.float32, device="cuda"), x.clone() if clone_input else x))
     s = hip.stream()
 
     def step(k):
-        t, d, audio = sets[k]
-        hip.check(lib.rcfm_tuner_load(t, hip.ptr(x), s))
+        t, d, audio, xk = sets[k]
+        hip.check(lib.rcfm_tuner_load(t, hip.ptr(xk), s))
         hip.check(lib.rcfm_pipeline_run(t, d, 0, C, hip.ptr(audio), s))
 
     for k in range(K):
@@ -66,4 +66,4 @@ def main(K=6, config="cfg4"):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 6, sys.argv[2] if len(sys.argv) > 2 else "cfg4")
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 6, sys.argv[2] if len(sys.argv) > 2 else "cfg4", len(sys.argv) > 3)
