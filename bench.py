@@ -12,6 +12,14 @@ buffer; every gather completes inside the timed region).
 Channels shard across ranks; the wideband FFT cannot shard by channel and is
 replicated, so total work is fixed as ranks grow: "scaling": "strong".
 
+`--gpus N` with N > 1 and no launcher around it starts its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N`), one process per GPU; under
+a launcher (WORLD_SIZE set) the world must equal --gpus.  An N > 1 launch times
+BOTH partitionings of the wideband FFT back to back: replicated (the line's
+`value`) and the rotating owner (block `rotating`, or its `error`).
+N = 1 allocates --placement-sets complete handle sets and reports the median
+one (`placement_spread` = fastest and slowest set).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
 `roofline` (dominant stage, algorithmic bytes per launch / HIP-event time per
 launch, against 8 TB/s) and, at N = 1, `cpu_baseline` (the numpy oracle timed on
@@ -458,7 +466,20 @@ def measure_cfg2_single(reps=200):
     return out
 
 
-def main():
+# rcfm_demod_set_option names (include/rcfm.h)
+DEMOD_OPTIONS = {"lds_chain": 1, "fused_tiles": 2, "phase_link": 3, "narrow_tiles": 4, "pilot_chain": 6, "decim_tile": 7,
+                 "lds_deemph": 8}
+
+
+def apply_options(lib, hip, demod, opts):
+    for item in opts:
+        name, _, value = item.partition("=")
+        if name not in DEMOD_OPTIONS or not value.lstrip("-").isdigit():
+            die("--opt %s: expected one of %s as NAME=INTEGER" % (item, ", ".join(sorted(DEMOD_OPTIONS))))
+        hip.check(lib.rcfm_demod_set_option(demod, DEMOD_OPTIONS[name], int(value)))
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -470,98 +491,226 @@ def main():
                     help="worker processes of the parallel ('fair') CPU baseline; 0 = size the pool from the host: "
                          "min(logical cores // 2, MemAvailable // 10 GB) -- each worker holds ~8 GB while it rolls "
                          "and windows the 240M-point spectrum; 1 = skip")
-    ap.add_argument("--parallelism", default="replicated", choices=["replicated", "rotating"],
+    ap.add_argument("--parallelism", default="both", choices=["both", "replicated", "rotating"],
                     help="N > 1: 'replicated' = every rank runs the whole wideband FFT and its own channels; 'rotating' = "
                          "rank i mod N owns buffer i (ingest + FFT) and sends each peer the spectrum bins its channels "
-                         "read over xGMI (radiocore.tools.sharding.SpectrumRing); both gather the audio with RCCL")
+                         "read over xGMI (radiocore.tools.sharding.SpectrumRing); both gather the audio with RCCL.  "
+                         "'both' (default) times replicated (the line's `value`) and then rotating in the same launch "
+                         "(block `rotating`, or its `error`); at N = 1 there is nothing to partition")
+    ap.add_argument("--placement-sets", type=int, default=4,
+                    help="N = 1: complete handle sets (tuner + demodulator + audio block) allocated side by side; each is "
+                         "timed over exactly K steps, `value` is the MEDIAN set and `placement_spread` the fastest and "
+                         "slowest (where hipMalloc puts the workspaces moves a cfg4 step by 1.5-4 %: "
+                         "profiles/r04_k_placement.md)")
+    ap.add_argument("--arena", type=int, default=-1,
+                    help="1: every handle set takes its workspaces from ONE device block (rcfm_arena_*), 0: from "
+                         "hipMalloc one by one; -1 = the default of this configuration")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="rcfm_demod_set_option on every demodulator handle of the timed legs (A/B runs: tools/ab_args.sh): "
+                         + ", ".join(sorted(DEMOD_OPTIONS)))
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other GPU configurations (cfg3, cfg5, batched cfg2) reported beside the headline")
-    ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr")
-    ap.add_argument("--pcie", action="store_true",
-                    help="also time the host-fed path: page-locked host buffer, H2D of buffer i+1 on a copy "
-                         "stream overlapped with the kernels of buffer i (extra field pcie_inclusive; never `value`); "
-                         "always on for N > 1")
-    args = ap.parse_args()
+    ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr as well")
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="skip the host-fed pass (page-locked host buffer, H2D of buffer i+1 on a copy stream overlapped "
+                         "with the kernels of buffer i: extra field pcie_inclusive, never `value`)")
+    ap.add_argument("--pcie", action="store_true", help=argparse.SUPPRESS)     # rounds 1-4 spelling: now the default
+    return ap.parse_args()
 
-    rank, world, local = dist_env()
-    if world > 1:
-        args.pcie = True           # the N > 1 line always carries pcie_inclusive (0.1 - 0.7 s of extra run time)
-    # Dry run of the N > 1 code on a one-GPU box (tests/test_bench_multirank.py): RCFM_BENCH_DEVICE puts every rank on
-    # that device and RCFM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); the audio blocks then
-    # travel through host memory.  The numbers of such a run mean nothing.
-    backend = os.environ.get("RCFM_BENCH_BACKEND", "nccl")
-    local = int(os.environ.get("RCFM_BENCH_DEVICE", local))
-    torch.cuda.set_device(local)
-    # RCFM_BENCH_FORCE_DIST=1 (tests/test_nccl_world1.py): a ONE-rank launch goes down the N > 1 code path -- RCCL
-    # process group, asynchronous double-buffered gather into views of the result, barrier, max-over-ranks -- which a
-    # one-GPU box can execute (a one-rank communicator is legal) although it cannot execute N > 1 itself.
-    multi = world > 1 or os.environ.get("RCFM_BENCH_FORCE_DIST") == "1"
-    # N > 1 only: a rank that stops making progress (a peer died, a transfer never matched) must end the run with a
-    # message instead of holding the node until the lease expires.  `phase` says where it was.
-    phase = {"name": "init", "step": -1, "t": time.monotonic()}
 
-    def progress(name, step=-1):
-        phase.update(name=name, step=step, t=time.monotonic())
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    if multi:
+
+def die(what, code=2, **more):
+    """A run that cannot measure what it was asked for ends with ONE JSON error line on stderr and a non-zero
+    status -- never with a contract line that describes something else."""
+    sys.stderr.write(json.dumps(dict({"error": what}, **more)) + "\n")
+    sys.stderr.flush()
+    sys.exit(code)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (how the driver starts N = 1): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <the same arguments>` -- one process per GPU, rank 0 prints the one line."""
+    have = torch.cuda.device_count()
+    if "RCFM_BENCH_DEVICE" not in os.environ and have < args.gpus:
+        die("bench.py --gpus %d: this node shows %d GPU(s)" % (args.gpus, have), gpus=args.gpus, visible=have)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+class Run:
+    """What every leg of one bench.py process shares: the rank's place in the world, the process group, the watchdog,
+    the library and the resident wideband buffer."""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank, self.world, local = dist_env()
+        # Dry run of the N > 1 code on a one-GPU box (tests/test_bench_multirank.py): RCFM_BENCH_DEVICE puts every rank
+        # on that device and RCFM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); the audio blocks
+        # then travel through host memory.  The numbers of such a run mean nothing.
+        self.backend = os.environ.get("RCFM_BENCH_BACKEND", "nccl")
+        self.local = int(os.environ.get("RCFM_BENCH_DEVICE", local))
+        # RCFM_BENCH_FORCE_DIST=1 (tests/test_nccl_world1.py): a ONE-rank launch goes down the N > 1 code path -- RCCL
+        # process group, asynchronous double-buffered gather into views of the result, barrier, max-over-ranks -- which
+        # a one-GPU box can execute (a one-rank communicator is legal) although it cannot execute N > 1 itself.
+        self.multi = self.world > 1 or os.environ.get("RCFM_BENCH_FORCE_DIST") == "1"
+        self.dist = None
+        self.rccl_ranks = None
+        # N > 1 only: a rank that stops making progress (a peer died, a transfer never matched) must end the run with a
+        # message instead of holding the node until the lease expires.  `phase` says where it was.
+        self.phase = {"name": "init", "step": -1, "t": time.monotonic(), "leg": "setup"}
+        self.limit = float(os.environ.get("RCFM_BENCH_TIMEOUT", "300"))
+        # the line of the legs that have finished: a later leg that fails still publishes them (rank 0)
+        self.finished = None
+
+    def progress(self, name, step=-1):
+        self.phase.update(name=name, step=step, t=time.monotonic())
+
+    def fail(self, what):
+        """End of the run from any thread.  While the SECOND partitioning of a 'both' launch runs, the first one's line
+        is already measured: rank 0 prints it with the failure in the `rotating` block and every rank leaves with
+        status 0 -- a first hardware run yields a number and a diagnosis, not a hung lease."""
+        ph = self.phase
+        msg = {"error": what, "rank": self.rank, "world": self.world, "phase": ph["name"], "step": ph["step"],
+               "parallelism": ph["leg"], "backend": self.backend}
+        sys.stderr.write(json.dumps(msg) + "\n")
+        sys.stderr.flush()
+        if ph["leg"] == "rotating (second leg)":
+            if self.rank == 0 and self.finished is not None:
+                self.finished["rotating"] = msg
+                sys.stdout.write(json.dumps(self.finished) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+        os._exit(3)
+
+    def start_group(self):
         import datetime
         import threading
         import torch.distributed as dist
+        self.dist = dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("RCFM_BENCH_FORCE_DIST") == "1":
             os.environ.setdefault("RCFM_GATHER_FORCE_COLLECTIVE", "1")   # exercise the collective on a one-rank group
-        limit = float(os.environ.get("RCFM_BENCH_TIMEOUT", "300"))
-
-        def fail(what):
-            sys.stderr.write(json.dumps({"error": what, "rank": rank, "world": world, "phase": phase["name"],
-                                         "step": phase["step"], "parallelism": args.parallelism, "backend": backend}) + "\n")
-            sys.stderr.flush()
-            os._exit(3)
 
         def watchdog():
             while True:
                 time.sleep(1.0)
-                idle = time.monotonic() - phase["t"]
-                if phase["name"] == "done":
+                idle = time.monotonic() - self.phase["t"]
+                if self.phase["name"] == "done":
                     return
-                if idle > limit:
-                    fail("bench.py made no progress for %.0f s" % idle)
+                if idle > self.limit:
+                    self.fail("bench.py made no progress for %.0f s" % idle)
 
         threading.Thread(target=watchdog, daemon=True).start()
-        to = datetime.timedelta(seconds=limit)
-        progress("process group rendezvous")
+        to = datetime.timedelta(seconds=self.limit)
+        self.progress("process group rendezvous")
         try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=to)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local), timeout=to)
             else:
-                dist.init_process_group(backend, timeout=to)
+                dist.init_process_group(self.backend, timeout=to)
         except Exception as e:                                   # a peer never arrived
-            fail("bench.py made no progress: process group rendezvous failed (%s: %s)" % (type(e).__name__, str(e)[:200]))
-        progress("process group up")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+            self.fail("bench.py made no progress: process group rendezvous failed (%s: %s)" % (type(e).__name__, str(e)[:200]))
+        self.progress("process group up")
+        if self.backend == "nccl":
+            # the communicator exists once a collective has run on it: its size is what RCCL saw
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            self.rccl_ranks = int(probe.item())
+        else:
+            self.rccl_ranks = 0          # dry run: no RCCL communicator at all
 
+    def max_over_ranks(self, seconds):
+        if not self.multi:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def fft_launch_names(lib, hip, N):
+    """The launches behind the stage `tuner_fft_N`: one k_fft_tile pass per factor of the forward plan."""
+    plan = hip.FftPlan()
+    if lib.rcfm_fft_describe(ctypes.c_int64(N), 0, ctypes.byref(plan)) != 0:
+        return ["rocFFT (length outside the engine)"]
+    return ["k_fft_tile<L=%d> (pass %d of %d)" % (plan.passes[i].L,
+                                                  i + 1, plan.npass) for i in range(plan.npass)]
+
+
+def stage_table(prof, N, B, A, kind, channels, steps=1):
+    """`stages` block: per stage of ONE step the HIP-event milliseconds, the number of launches, and the algorithmic
+    bytes those launches account for (stage_bytes x units) -- every roofline figure of the line can be recomputed
+    from this block: frac = bytes / (ms * 1e-3) / 8e12."""
+    out = {}
+    for k, (st, ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if cnt == 0:
+            continue
+        by = stage_bytes(k, N, B, A, kind) * (1 if k == "tuner_fft_N" else channels)
+        out[k] = {"ms": round(ms / steps, 4), "launches": cnt / steps, "algorithmic_bytes": by,
+                  "TBps": round(by / (ms / steps * 1e-3) / 1e12, 3) if ms else 0.0}
+    return out
+
+
+def measure_partitioning(run, x, centres, f_in, parallelism, primary):
+    """One leg: K timed steps of the hot path under one partitioning of the work over the ranks.  `primary`: the leg
+    the line's `value` comes from (N = 1: also cpu_baseline, parity spot check)."""
+    args, rank, world, multi, backend = run.args, run.rank, run.world, run.multi, run.backend
+    dist = run.dist
+    progress = run.progress
     from radiocore._internal import hip
+    from radiocore.tools import sharding
     lib = hip.lib()
-    hip.torch()
-
     N, C, B, A, raster, kind = CONFIGS[args.config]
     ch = 2 if kind == "WBFM" else 1
-    x, centres, f_in = synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
+    rotating = parallelism == "rotating"
 
     # this rank's contiguous share of the channels (SURVEY.md section 8e)
-    from radiocore.tools import sharding
     lo, hi = sharding.channel_range(rank, world, C)
     mine = hi - lo
     rolls = [int(f_in - f) for f in centres]
     roll_a = (ctypes.c_int64 * C)(*rolls)
     bw_a = (ctypes.c_int32 * C)(*([B] * C))
-    tuner = ctypes.c_void_p()
-    hip.check(lib.rcfm_tuner_create(N, C, roll_a, bw_a, ctypes.byref(tuner)))
-    hip.check(lib.rcfm_tuner_shard(tuner, lo, mine))   # the wideband FFT keeps only what this rank's channels read
-    demod = ctypes.c_void_p()
     kind_id = {"FM": 0, "MFM": 1, "WBFM": 2}[kind]
-    hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
-    rotating = args.parallelism == "rotating"
+    # N > 1: the audio blocks are double-buffered so that the gather of buffer i (RCCL's own stream, xGMI)
+    # overlaps the kernels of buffer i+1; every gather completes inside the timed region (barrier()).
+    nbuf = 2 if multi else 1
+    # N = 1: several complete handle sets side by side (their workspaces land on different memory: placement_spread)
+    nsets = max(1, args.placement_sets) if (not multi and not rotating) else 1
+    use_arena = bool(args.arena) if args.arena >= 0 else False
+    sets = []
+    for k in range(nsets):
+        arena = ctypes.c_void_p()
+        if use_arena:
+            # one block for the whole set: the tuner's spectrum + scratch (16 N bytes) and the per-chunk workspaces
+            # (at most ~64 bytes per channel sample of a chunk); whatever does not fit goes to a second block
+            chunk_ch = args.chunk if args.chunk > 0 else min(8192, max(1024, 1024 * 240000 // B))
+            want = int(17.6 * N + 64.0 * min(mine, chunk_ch) * B) + (1 << 30)
+            hip.check(lib.rcfm_arena_create(ctypes.c_size_t(want), ctypes.byref(arena)))
+            hip.check(lib.rcfm_arena_bind(arena))
+        tuner, demod = ctypes.c_void_p(), ctypes.c_void_p()
+        hip.check(lib.rcfm_tuner_create(N, C, roll_a, bw_a, ctypes.byref(tuner)))
+        hip.check(lib.rcfm_tuner_shard(tuner, lo, mine))   # the wideband FFT keeps only what this rank's channels read
+        hip.check(lib.rcfm_demod_create(kind_id, C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
+        apply_options(lib, hip, demod, args.opt)
+        if use_arena:
+            hip.check(lib.rcfm_arena_bind(None))
+        sets.append({"tuner": tuner, "demod": demod, "arena": arena,
+                     "audios": [torch.empty((mine, A, ch), dtype=torch.float32, device="cuda") for _ in range(nbuf)]})
+    cur = {"set": sets[0]}
+    tuner, demod = sets[0]["tuner"], sets[0]["demod"]
     ring = surf = None
     if rotating:
         # the rotating owner runs through the class surface (Tuner + one demodulator object per channel): the ring
@@ -574,11 +723,6 @@ def main():
         ring = sharding.SpectrumRing(surf, N, C)
         for j in range(ring.lookahead):                       # prime: `lookahead` buffers in flight from here on
             ring.submit(j, x if ring.owner(j) == rank else None)
-    # N > 1: the audio blocks are double-buffered so that the gather of buffer i (RCCL's own stream, xGMI)
-    # overlaps the kernels of buffer i+1; every gather completes inside the timed region (barrier()).
-    nbuf = 2 if multi else 1
-    audios = [torch.empty((mine, A, ch), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-    audio = audios[0]
     gathereds = [torch.empty((C, A, ch), dtype=torch.float32, device="cuda") if (multi and rank == 0) else None
                  for _ in range(nbuf)]
     in_flight = [None] * nbuf
@@ -589,6 +733,7 @@ def main():
         s = hip.stream()
         slot = counter[0] % nbuf
         counter[0] += 1
+        hs = cur["set"]
         if in_flight[slot] is not None:
             in_flight[slot].wait()          # stream-ordered: this slot's previous block has left
             in_flight[slot] = None
@@ -597,15 +742,15 @@ def main():
             j = i + ring.lookahead
             ring.submit(j, source[0] if ring.owner(j) == rank else None)   # owner of buffer j: ingest + FFT + sends
             ring.acquire(i)                                                # buffer i's bins for this rank's channels
-            audios[slot] = surf.run_all(numpy_output=False)
+            hs["audios"][slot] = surf.run_all(numpy_output=False)
         else:
-            hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), s))
+            hip.check(lib.rcfm_tuner_load(hs["tuner"], hip.ptr(x), s))
             # pipeline_run addresses channels of tuner and demod by the same index
-            hip.check(lib.rcfm_pipeline_run(tuner, demod, lo, mine, hip.ptr(audios[slot]), s))
+            hip.check(lib.rcfm_pipeline_run(hs["tuner"], hs["demod"], lo, mine, hip.ptr(hs["audios"][slot]), s))
         if multi and backend == "nccl":     # RCCL over xGMI: the only collective on the path
-            in_flight[slot] = sharding.gather_audio(audios[slot], C, dst=0, out=gathereds[slot], async_op=True)
+            in_flight[slot] = sharding.gather_audio(hs["audios"][slot], C, dst=0, out=gathereds[slot], async_op=True)
         elif multi:                         # dry run: same protocol through host memory
-            got = sharding.gather_audio(audios[slot].cpu(), C, dst=0)
+            got = sharding.gather_audio(hs["audios"][slot].cpu(), C, dst=0)
             if rank == 0:
                 gathereds[slot].copy_(got)
 
@@ -619,56 +764,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        progress("warm-up", k)
-        step()
+    def profile_pass(steps_):
+        """Untimed: `steps_` steps with every stage bracketed by HIP events on the stream the kernels run on."""
+        lib.rcfm_profile_reset()
+        lib.rcfm_profile_enable(ctypes.c_uint64((1 << lib.rcfm_profile_stage_count()) - 1))
+        for _ in range(steps_):
+            step()
+        torch.cuda.synchronize()
+        prof = {k: (st, ms / steps_, cnt / steps_) for k, (st, ms, cnt) in read_profile(lib).items()}
+        lib.rcfm_profile_enable(ctypes.c_uint64(0))
+        return prof
+
+    for hs in sets:
+        cur["set"] = hs
+        for k in range(args.warmup):
+            progress("warm-up", k)
+            step()
     progress("warm-up barrier")
     barrier()
 
     # pass 1 (untimed): every stage bracketed, to find the dominant one
-    lib.rcfm_profile_reset()
-    lib.rcfm_profile_enable(ctypes.c_uint64((1 << lib.rcfm_profile_stage_count()) - 1))
+    cur["set"] = sets[0]
     prof_steps = world if rotating else 1      # a rank runs the wideband FFT once per `world` buffers when it rotates
-    for _ in range(prof_steps):
-        step()
-    torch.cuda.synchronize()
-    prof_all = {k: (st, ms / prof_steps, cnt) for k, (st, ms, cnt) in read_profile(lib).items()}
-    lib.rcfm_profile_enable(ctypes.c_uint64(0))
+    prof_all = profile_pass(prof_steps)
     dominant = max(prof_all, key=lambda k: prof_all[k][1])
-    if args.profile_all and rank == 0:
-        tot = sum(v[1] for v in prof_all.values())
-        for k, (st, ms, cnt) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
-            per = ms / max(cnt, 1)
-            by = stage_bytes(k, N, B, A, kind) * (1 if k == "tuner_fft_N" else mine / max(cnt, 1))
-            print("%-16s %9.3f ms  %5d launches  %8.1f us each  %6.2f TB/s algorithmic  %4.1f%%" %
-                  (k, ms, cnt, per * 1e3, by / (per * 1e-3) / 1e12 if per else 0, 100 * ms / tot), file=sys.stderr)
 
-    # timed region: exactly K steps, barrier + synchronize on both sides; only the
-    # dominant stage keeps its event pairs (on the stream the kernels run on)
-    lib.rcfm_profile_reset()
-    lib.rcfm_profile_enable(ctypes.c_uint64(1 << prof_all[dominant][0]))
-    if ring is not None:
-        ring.enable_timing()
-    progress("barrier before the timed region")
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        progress("timed step", k)
-        step()
-    progress("barrier after the timed region")
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # timed region: exactly K steps, barrier + synchronize on both sides; only the dominant stage keeps its event
+    # pairs (on the stream the kernels run on).  N = 1: once per handle set, the MEDIAN set is the line's value.
+    timed = []
+    for hs in sets:
+        cur["set"] = hs
+        lib.rcfm_profile_reset()
+        lib.rcfm_profile_enable(ctypes.c_uint64(1 << prof_all[dominant][0]))
+        progress("barrier before the timed region")
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            progress("timed step", k)
+            step()
+        progress("barrier after the timed region")
+        barrier()
+        dt = time.perf_counter() - t0
+        timed.append((dt, read_profile(lib)[dominant], hs))
+        lib.rcfm_profile_enable(ctypes.c_uint64(0))
+    order = sorted(range(len(timed)), key=lambda i: timed[i][0])
+    pick = order[len(order) // 2]                 # 4 sets: the third fastest (the upper median)
+    elapsed, dom, median_set = timed[pick]
     own_elapsed = elapsed
-    dom = read_profile(lib)[dominant]
-    lib.rcfm_profile_enable(ctypes.c_uint64(0))
+    cur["set"] = median_set
+    tuner, demod = median_set["tuner"], median_set["demod"]
+    audio = median_set["audios"][0]
+    if nsets > 1:                                 # the decomposition of the set the value comes from
+        prof_all = profile_pass(1)
 
     per_rank = None
     if multi:
         progress("max over ranks")
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        # where each rank's step went (HIP-event stage times of the untimed profile pass; the ring's own event pairs):
+        elapsed = run.max_over_ranks(elapsed)
+        # where each rank's step went (HIP-event stage times of the untimed profile pass; the ring's own event pairs,
+        # collected in a pass of their own AFTER the timed region: the timed steps carry no instrumentation):
         # the first thing to read when a multi-GPU number looks wrong
         fft_pb = prof_all["tuner_fft_N"][1]                       # per buffer of this rank (rotating: one in `world`)
         chan_pb = sum(v[1] for k, v in prof_all.items() if k != "tuner_fft_N")
@@ -676,7 +830,13 @@ def main():
         row = {"rank": rank, "channels": mine, "step_ms": round(mine_ms, 4), "fft_ms": round(fft_pb, 4),
                "chan_ms": round(chan_pb, 4), "send_ms": 0.0, "wait_ms": 0.0}
         if ring is not None:
+            progress("ring timing pass")
+            ring.enable_timing()
+            for _ in range(2 * world):
+                step()
+            barrier()
             tsum = ring.timing_summary() or {}
+            ring.disable_timing()
             row.update(fft_ms=tsum.get("fft_ms", 0.0), send_ms=tsum.get("send_ms", 0.0), wait_ms=tsum.get("wait_ms", 0.0),
                        owned_buffers=tsum.get("fft_count", 0))
         row["other_ms"] = round(mine_ms - row["chan_ms"] - row["wait_ms"] - (0.0 if rotating else row["fft_ms"]), 4)
@@ -703,6 +863,7 @@ def main():
     if args.config == "cfg4" and world == 1 and args.chunk == 0:
         traffic, traffic_source, traffic_stale = provenance.stage_traffic(dominant)
 
+    launches = fft_launch_names(lib, hip, N) if dominant == "tuner_fft_N" else [dominant]
     result = {
         "metric": "IQ Msamples/s through Tuner+%s at %d channels" % (kind, C),
         "value": round(value, 2),
@@ -732,14 +893,30 @@ def main():
         "path_algorithmic_read_GB": round(total_read / 1e9, 3),
         "kernel_source_sha": provenance.kernel_source_sha(),
         "roofline": {
-            "bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
+            "bound": "hbm", "kernel": " + ".join(launches), "stage": dominant,
+            "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_stale": traffic_stale,
             "traffic_source": traffic_source,
             "launch_us": round(per_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
+            "kernel_launches_per_stage_launch": len(launches),
             "algorithmic_bytes_per_launch": alg_bytes,
             "share_of_step": round(dom[1] / args.steps / ms_per_step, 3),
+            "note": "a stage launch = the %d kernel launches named in `kernel`, bracketed by one HIP-event pair on their "
+                    "stream inside the timed region; achieved = algorithmic_bytes_per_launch / launch_us" % len(launches),
         },
+        # one step of the set `value` comes from, every stage bracketed (untimed pass after the timed region)
+        "stages": stage_table(prof_all, N, B, A, kind, mine),
     }
+    if nsets > 1:
+        per_set = [round(1e3 * t[0] / args.steps, 4) for t in timed]
+        result["placement_spread"] = [min(per_set), max(per_set)]
+        result["placement"] = {
+            "handle_sets": nsets, "ms_per_step_by_set": per_set, "value_from_set": pick, "arena": use_arena,
+            "note": "%d complete handle sets side by side, each timed over exactly %d steps between barriers; `value` / "
+                    "`ms_per_step` / `roofline` / `stages` are the set with the median time (upper median of an even "
+                    "count)" % (nsets, args.steps)}
+    if multi:
+        result["rccl_ranks"] = run.rccl_ranks
 
     if multi:
         # Channel sharding scales the per-channel stages; the replicated wideband FFT does not.
@@ -763,6 +940,8 @@ def main():
         if rotating:
             result["rotating_owner"] = {
                 "lookahead": ring.lookahead, "spectrum_slots": len(ring.slots),
+                "full_slots": ring.full_slots, "window_slots": ring.window_slots,
+                "slot_bytes": int(ring.slot_bytes()),
                 "window_bins_of_rank0": int(sum(b - a for a, b in ring.segments[0])),
                 "bytes_sent_per_owned_buffer": int(ring.bytes_sent_per_buffer()),
                 "ffts_per_rank_per_buffer": round(1.0 / world, 4)}
@@ -778,20 +957,21 @@ def main():
                 "finite": bool(torch.isfinite(g).all().item()),
                 "blocks_with_audio": int(sum(bool((g[a:b].abs().amax() > 1e-3).item()) for a, b in bounds if b > a)),
                 "blocks": int(sum(1 for a, b in bounds if b > a)),
-                "own_block_equal": bool(torch.equal(g[lo:hi], audios[(counter[0] - 1) % nbuf])),
+                "own_block_equal": bool(torch.equal(g[lo:hi], cur["set"]["audios"][(counter[0] - 1) % nbuf])),
             }
 
-    if args.pcie:
+    if not args.no_pcie:
         # Host-fed variant (DESIGN.md sections 4, 5): the wideband buffer starts in page-locked host memory
         # (radiocore.tools.Buffer(cuda=True)) and crosses PCIe inside the loop.
         #   replicated: EVERY rank copies the whole buffer over its own link (radiocore.tools.Feeder: two device
         #               slots, buffer i+1 copied on its own stream under the kernels of buffer i);
         #   rotating:   only the owner of a buffer copies it (SpectrumRing stages it on its FFT stream), so each link
         #               carries 1/N of the buffers.
+        progress("host-fed pass")
         from radiocore.tools import Buffer, Feeder
         host = Buffer(N, dtype=np.complex64, cuda=True)
         host.data[:] = x.cpu().numpy()
-        k = max(args.steps, 4)
+        k = max(min(args.steps, 10), 4)
         if rotating:
             source[0] = host._owner.view(torch.complex64)      # the same pinned pages as a torch tensor
             for _ in range(ring.lookahead + 1):                 # the buffers already in flight came from HBM
@@ -825,12 +1005,9 @@ def main():
             dt = (time.perf_counter() - t0) / k
             note = ("radiocore.tools.Feeder: page-locked host buffer, H2D of buffer i+1 overlapped with the kernels of "
                     "buffer i" + ("; every rank copies the whole buffer over its own link" if world > 1 else ""))
-        if multi:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+        dt = run.max_over_ranks(dt)
         result["pcie_inclusive"] = {"ms_per_step": round(dt * 1e3, 3), "value": round(N / dt / 1e6, 1),
-                                    "unit": "Msamples/s", "h2d_GBps": None, "note": note}
+                                    "unit": "Msamples/s", "steps": k, "h2d_GBps": None, "note": note}
         if not rotating:
             t0 = time.perf_counter()
             feeder.submit(host.data)
@@ -841,7 +1018,8 @@ def main():
             feeder.close()
         del host
 
-    if rank == 0 and world == 1 and args.cpu_channels > 0 and not rotating and not multi:
+    if primary and rank == 0 and world == 1 and args.cpu_channels > 0 and not rotating and not multi:
+        progress("cpu baseline")
         x_host = x.cpu().numpy()
         ref_audio, result["cpu_baseline"] = cpu_baseline(x_host, f_in, centres, N, C, B, A, kind,
                                                          args.cpu_channels, fair_workers(args.cpu_workers))
@@ -851,26 +1029,93 @@ def main():
         hip.check(lib.rcfm_demod_reset_state(demod, hip.stream()))
         step()
         torch.cuda.synchronize()
-        got = audio.cpu().numpy()
+        got = cur["set"]["audios"][(counter[0] - 1) % nbuf].cpu().numpy()
         worst = 0.0
         for i, want in ref_audio.items():
             want = np.asarray(want).reshape(A, ch)
             worst = max(worst, float(np.max(np.abs(got[i] - want)) / np.max(np.abs(want))))
         result["parity_vs_oracle"] = {"channels": sorted(ref_audio), "max_rel_err": worst, "tol": 1e-4}
-    elif rank == 0:
+    elif primary and rank == 0:
         result["cpu_baseline"] = None
 
+    progress("leg teardown")
     if rotating:
         ring.drain()               # the buffers still in flight: every posted transfer completes before the group goes
         torch.cuda.synchronize()
-    hip.check(lib.rcfm_demod_destroy(demod))
-    hip.check(lib.rcfm_tuner_destroy(tuner))
+        ring.close()
+        del ring, surf
+    barrier()
+    for hs in sets:
+        hip.check(lib.rcfm_demod_destroy(hs["demod"]))
+        hip.check(lib.rcfm_tuner_destroy(hs["tuner"]))
+        if hs["arena"]:
+            hip.check(lib.rcfm_arena_destroy(hs["arena"]))
+    del sets, gathereds, cur, median_set, audio, timed
+    torch.cuda.empty_cache()
+    return result, (roll_a, bw_a)
+
+
+ROTATING_KEYS = ("value", "unit", "ms_per_step", "steps", "path_hbm_frac", "amdahl_bound_speedup", "per_rank",
+                 "rotating_owner", "channel_stage_value", "gather_check", "pcie_inclusive", "stages", "roofline")
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        die("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                      # does not return
+    run = Run(args)
+    if run.world != args.gpus:
+        # a launcher's world that is not what --gpus asked for is a mis-launch, whichever way round: refuse it rather
+        # than print a line whose n_gpus differs from the request
+        die("bench.py --gpus %d runs inside a world of %d rank(s): launch `python bench.py --gpus N` (it starts its own "
+            "ranks) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, run.world),
+            gpus=args.gpus, world=run.world, rank=run.rank)
+    torch.cuda.set_device(run.local)
+    if run.multi:
+        run.start_group()
+
+    from radiocore._internal import hip
+    lib = hip.lib()
+    hip.torch()
+
+    N, C, B, A, raster, kind = CONFIGS[args.config]
+    x, centres, f_in = synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
+
+    legs = ["replicated", "rotating"] if (args.parallelism == "both" and run.world > 1) else \
+           ["replicated" if args.parallelism == "both" else args.parallelism]
+    run.phase["leg"] = legs[0]
+    result, (roll_a, bw_a) = measure_partitioning(run, x, centres, f_in, legs[0], primary=True)
+    rank, world, multi = run.rank, run.world, run.multi
+    if len(legs) > 1:
+        # the second partitioning in the same launch: its own watchdog budget, its failure is a block of the line
+        run.finished = result
+        run.phase["leg"] = "rotating (second leg)"
+        run.limit = float(os.environ.get("RCFM_BENCH_TIMEOUT_ROTATING", min(run.limit, 120.0)))
+        run.progress("second leg: rotating FFT owner")
+        try:
+            if os.environ.get("RCFM_BENCH_FAIL_ROTATING") == "1" and run.rank == 1:      # tests/test_bench_multirank.py
+                raise RuntimeError("injected failure of the rotating leg")
+            second, _ = measure_partitioning(run, x, centres, f_in, "rotating", primary=False)
+            block = {k: second[k] for k in ROTATING_KEYS if k in second}
+            block["parallelism"] = second["config"]["parallelism"]
+            block["vs_replicated"] = round(second["value"] / result["value"], 4) if result["value"] else None
+            result["rotating"] = block
+        except Exception as e:
+            # the peers are somewhere inside the leg's collectives: no way to tell them -- publish and leave
+            run.fail("rotating leg raised %s: %s" % (type(e).__name__, str(e)[:300]))
+        run.finished = None
+        run.phase["leg"] = "done"
+
+    ms_per_step = result["ms_per_step"]
     if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras and not multi:
         # the other GPU configurations of BASELINE.json on the same box, outside the headline's timed region
+        run.progress("other configurations")
         result["pipelined"] = measure_lanes(lib, hip, x, roll_a, bw_a, N, C, B, A, kind, args.steps, args.warmup,
                                             ms_per_step * 1e-3)
         surface4 = measure_surface("cfg4", x, centres, args.steps, args.warmup, ms_per_step * 1e-3)
-        del x, audios, audio
+        del x
         torch.cuda.empty_cache()
         result["other_configs"] = {
             "cfg3": measure_config("cfg3", lib, hip, 50, 5),
@@ -885,11 +1130,18 @@ def main():
         # the class surface (Tuner.load + Tuner.run_all) against the raw ABI calls of the timed region
         result["surface"] = {"cfg4": surface4, "cfg5": result["other_configs"]["cfg5"].pop("surface"),
                              "cfg3": result["other_configs"]["cfg3"].pop("surface")}
+    if args.profile_all and rank == 0:
+        tot = sum(v["ms"] for v in result["stages"].values())
+        for k, v in result["stages"].items():
+            print("%-16s %9.3f ms  %5d launches  %8.1f us each  %6.2f TB/s algorithmic  %4.1f%%" %
+                  (k, v["ms"], v["launches"], 1e3 * v["ms"] / max(v["launches"], 1), v["TBps"], 100 * v["ms"] / tot),
+                  file=sys.stderr)
     if rank == 0:
         print(json.dumps(result))
-    progress("done")
+        sys.stdout.flush()
+    run.progress("done")
     if multi:
-        dist.destroy_process_group()
+        run.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

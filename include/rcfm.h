@@ -19,6 +19,10 @@
  *     reference is driven by one DSP thread, examples/multi_fm_server.py:86-106);
  *   - inputs are never modified; outputs are caller-owned; state and
  *     workspaces are owned by the handle and released by *_destroy.
+ *   - the library reads ONE environment variable, once per process: RCFM_FFT=rocfft
+ *     routes every transform through rocFFT (safety net and A/B partner; the
+ *     default is the hand-written engine, rocFFT only for lengths outside it).
+ *     Every other choice is an argument or a *_set_option of a handle;
  *   - batched arrays are channel-major and contiguous: iq [C][B] complex64,
  *     audio [C][A][ch] float32 (ch = 1 for FM/MFM, 2 = interleaved L,R for WBFM,
  *     the byte layout of the reference's (1, A, 2) array, wbfm.py:94).
@@ -55,6 +59,7 @@ typedef struct rcfm_demod_s* rcfm_demod_t;
 typedef struct rcfm_resampler_s* rcfm_resampler_t;
 typedef struct rcfm_feeder_s* rcfm_feeder_t;
 typedef struct rcfm_comm_s* rcfm_comm_t;
+typedef struct rcfm_arena_s* rcfm_arena_t;
 
 /* ---- library / device ---------------------------------------------------- */
 
@@ -75,6 +80,24 @@ int rcfm_stream_sync(void* stream);
  * one (or any hipStream_t, or NULL for the default stream). */
 int rcfm_stream_create(void** stream);
 int rcfm_stream_destroy(void* stream);
+
+/* ---- placement of the library's workspaces (no reference counterpart: numpy / cupy allocate per call) ------------
+ * Where hipMalloc puts a multi-GB workspace moves the kernels that stream through it by 1.5 - 4 % of a cfg4 buffer, and
+ * the draw differs from handle to handle and from process to process (profiles/r04_k_placement.md).  A host that wants
+ * ONE draw for a whole handle set, or wants to choose it (create several arenas, time its own workload in each, keep
+ * the best), creates an arena: device memory taken in blocks of `block_bytes` (0: 1 GiB blocks, taken on demand; a
+ * request larger than a block gets a block of its own) and handed out by a bump pointer on 2 MiB boundaries.
+ *   bind      arena != NULL: tuner / demodulator handles CREATED by this thread from now on belong to the arena -- every
+ *             workspace of 1 MiB or more they ever allocate (at creation and later, whichever thread calls) comes from
+ *             it; NULL: back to hipMalloc per workspace (the default; existing handles keep their arena)
+ *   stats     bytes reserved from the device, bytes handed out, pieces still owned by live handles
+ *   destroy   RCFM_ERR_STATE while a handle created inside the arena is alive (pieces return with the arena, not one
+ *             by one: a handle set that is rebuilt often should get a fresh arena)
+ * Results do not depend on any of this.  bench.py --arena 1, tools/placement_sets.py. */
+int rcfm_arena_create(size_t block_bytes, rcfm_arena_t* out);
+int rcfm_arena_bind(rcfm_arena_t arena);
+int rcfm_arena_stats(rcfm_arena_t arena, size_t* reserved_bytes, size_t* used_bytes, size_t* live_pieces);
+int rcfm_arena_destroy(rcfm_arena_t arena);
 
 /* ---- Tuner (radiocore/tools/tuner.py) ------------------------------------ */
 
@@ -109,11 +132,25 @@ int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X);
  *   window            the bins channels [first, first + count) read: [first_bin, first_bin + nbins) modulo n, whole
  *                     rows of the forward plan (nbins = n: no window, everything)
  *   adopt             the caller has written those bins into the storage (received them over xGMI): refresh the
- *                     halos and accept exactly that channel range in rcfm_tuner_run / rcfm_pipeline_run          */
+ *                     halos and accept exactly that channel range in rcfm_tuner_run / rcfm_pipeline_run
+ *   window_layout     a rank that never OWNS a given buffer needs room for its window only: storage =
+ *                     [halo | nbins | halo] complex64, the window's first bin at element `halo` (at G = 8 an eighth of
+ *                     a spectrum per slot instead of a whole one).  RCFM_ERR_SIZE when the window wraps around bin 0
+ *                     or touches the far ends (their halos repeat the other end): such a rank keeps whole slots
+ *   attach_window     use such a storage for channels [first, first + count): receive the window's bins into
+ *                     elements [halo, halo + nbins), then adopt(first, count).  rcfm_tuner_load and
+ *                     rcfm_tuner_spectrum fail with RCFM_ERR_STATE while a window is attached; channels outside
+ *                     the range are refused.  attach_spectrum (storage or NULL) ends it.                          */
 int rcfm_tuner_spectrum_layout(rcfm_tuner_t t, int64_t* halo, int64_t* n);
 int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, int loaded_count);
 int rcfm_tuner_window(rcfm_tuner_t t, int first, int count, int64_t* first_bin, int64_t* nbins);
+int rcfm_tuner_window_layout(rcfm_tuner_t t, int first, int count, int64_t* halo, int64_t* nbins);
+int rcfm_tuner_attach_window(rcfm_tuner_t t, void* storage, int first, int count);
 int rcfm_tuner_adopt(rcfm_tuner_t t, int first, int count, void* stream);
+/* Which tile width rcfm_tuner_run uses (rcfm_pipeline_run passes the demodulator's RCFM_OPT_NARROW_TILES instead):
+ * 0 = always 16 lines per tile, 1 (default) = 8 when a launch has fewer than two 16-line tiles per CU, 2 = always 8. */
+enum { RCFM_TUNER_OPT_NARROW_TILES = 1 };
+int rcfm_tuner_set_option(rcfm_tuner_t t, int option, int value);
 int rcfm_tuner_destroy(rcfm_tuner_t t);
 
 /* ---- demodulators (radiocore/analog/{fm,mfm,wbfm}.py) --------------------- */
@@ -152,11 +189,17 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *   RCFM_OPT_LDS_CHAIN    narrow FM / MFM channels run tuner + demodulator of a channel pair in one workgroup (0: the
  *                         multi-pass launches)
  *   RCFM_OPT_FUSED_TILES  two transforms per tile: pilot chain, Hilbert mask, stereo mix, spectral decimation between
- *                         transforms (0: one transform per launch, the intermediate spectra go through memory)
+ *                         transforms (0: one transform per launch, the intermediate spectra go through memory); sets
+ *                         the two switches below together
+ *   RCFM_OPT_PILOT_CHAIN  ... only the tiles around the Hilbert mask (pilot pair FFT -> mask -> IFFT -> stereo matrix)
+ *   RCFM_OPT_DECIM_TILE   ... only the spectral decimation between FFT_B's last pass and IFFT_A's first
+ *   RCFM_OPT_LDS_DEEMPH   narrow MFM channels: de-emphasis, mean removal and clip inside the LDS chain (0: the
+ *                         de-emphasis launches behind it)
  *   RCFM_OPT_PHASE_LINK   the tuner hands the demodulator angle(x) / pi as float32 (0: complex64 samples, as
  *                         tuner.py:161 returns them)
  *   RCFM_OPT_NARROW_TILES the tile kernels exist with 16 and with 8 lines per tile: 0 = always 16, 1 (default) = 8 when a
- *                         launch has fewer than two 16-line tiles per CU (one WBFM.run per call, the reference's harness
+ *                         launch has fewer than two 16-line tiles per CU; applies to the demodulator's kernels and, in
+ *                         rcfm_pipeline_run, to the tuner's inverse FFT of the same chunk (one WBFM.run per call, the reference's harness
  *                         shape tests/benchmark.py:29-31: 60 short tiles instead of 30 long ones), 2 = always 8
  *   RCFM_OPT_STATE_FENCE  (default 0) consecutive buffers on DIFFERENT streams: the reference's loop
  *                         (examples/multi_fm_server.py:98-106) handles one buffer at a time; a host that keeps two handle
@@ -166,7 +209,8 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *                         from buffer i (deemphasis.py:64): with the fence on, every launch sequence that touches the
  *                         shared state waits for the event the previous one recorded, on whichever stream that was.
  *                         Set it on any ONE handle of the sharing group, after the binding */
-enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5 };
+enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5,
+       RCFM_OPT_PILOT_CHAIN = 6, RCFM_OPT_DECIM_TILE = 7, RCFM_OPT_LDS_DEEMPH = 8 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 
@@ -284,6 +328,11 @@ int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length *
 /* Unnormalised forward (inverse = 0) or conjugate (inverse = 1) transform of `batch`
  * contiguous length-n complex64 signals; in == out allowed.  (scipy.fft.fft / ifft*n) */
 int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);
+/* The same transform with the pass lengths given by the caller (their product is n, each within the engine's tile
+ * lengths; RCFM_ERR_ARG otherwise): plan sweeps (tools/plan_sweep.py) and tests that put a tile length into a role the
+ * planner does not use it in (tests/test_hip_fft.py). */
+int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int batch, int inverse, const void* in,
+                      void* out, void* stream);
 /* The same transform through rocFFT (any n): the A/B partner of rcfm_fft_c2c in
  * tools/bench_fft.py and the fallback for lengths the engine refuses. */
 int rcfm_fft_c2c_rocfft(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);

@@ -33,6 +33,56 @@ thread_local std::string g_last_error;
 
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 
+// ---- arena (common.h; rcfm_arena_* below) ---------------------------------------------------------------------------
+}  // namespace rcfm
+struct rcfm_arena_s {
+    std::mutex mu;
+    size_t block_bytes = 0;                 // size of a block (a request larger than that gets a block of its own size)
+    struct Block {
+        char* base;
+        size_t bytes, used;
+    };
+    std::vector<Block> blocks;
+    size_t live = 0;                        // pieces handed out and not yet dropped
+    ~rcfm_arena_s() {
+        for (auto& b : blocks) (void)hipFree(b.base);
+    }
+};
+namespace rcfm {
+
+namespace {
+thread_local Arena* g_arena = nullptr;
+constexpr size_t kArenaAlign = (size_t)2 << 20;   // pieces start on 2 MiB boundaries (the large-page size)
+}  // namespace
+
+Arena* current_arena() { return g_arena; }
+
+void* arena_take(Arena* a, size_t bytes) {
+    std::lock_guard<std::mutex> lock(a->mu);
+    const size_t need = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+    for (auto& b : a->blocks)
+        if (b.bytes - b.used >= need) {
+            void* p = b.base + b.used;
+            b.used += need;
+            a->live += 1;
+            return p;
+        }
+    void* base = nullptr;
+    const size_t sz = std::max(a->block_bytes, need);
+    RC_HIP(hipMalloc(&base, sz));
+    a->blocks.push_back(Arena::Block{static_cast<char*>(base), sz, need});
+    a->live += 1;
+    return base;
+}
+
+void arena_drop(Arena* a) {
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (a->live) a->live -= 1;
+}
+
+ArenaScope::ArenaScope(Arena* a) : prev(g_arena) { g_arena = a; }
+ArenaScope::~ArenaScope() { g_arena = prev; }
+
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -256,26 +306,21 @@ using namespace rcfm;
 // handles
 // ---------------------------------------------------------------------------
 
-// RCFM_FFT=rocfft routes every transform through rocFFT (A/B runs and a safety net).
-// RCFM_NARROW_TILES (environment, read once; per demodulator handle: rcfm_demod_set_option): 0 = every tile kernel with 16
-// lines per tile, 1 (default) = 8 lines when a launch would leave most CUs without a tile, 2 = always 8.
-static int narrow_default() {
-    static const int v = [] {
-        const char* e = std::getenv("RCFM_NARROW_TILES");
-        return e ? std::atoi(e) : 1;
-    }();
-    return v;
-}
+// Tile width (RCFM_OPT_NARROW_TILES / RCFM_TUNER_OPT_NARROW_TILES, per handle): 0 = every tile kernel with 16 lines per
+// tile, 1 (default) = 8 lines when a launch would leave most CUs without a tile, 2 = always 8.
+constexpr int kNarrowDefault = 1;
 // One tile per CU and a half-empty chip: that is where a launch lasts one tile's latency and narrower tiles (twice as
 // many, half the threads each) shorten it.  From two 16-line tiles per CU on, the wide ones stream better.
-static bool narrow_launch(const FftEngine& e, int signals, int mode = -1) {
-    if (mode < 0) mode = narrow_default();
+static bool narrow_launch(const FftEngine& e, int signals, int mode) {
     if (mode == 0) return false;
     if (mode >= 2) return true;
     const int64_t tiles = (e.desc().pass[0].n_inner + kFftTileW - 1) / kFftTileW;
     return (int64_t)signals * tiles < 2 * (int64_t)FftEngine::compute_units();
 }
 
+// RCFM_FFT=rocfft (environment, read once per process; include/rcfm.h): every transform through rocFFT -- the safety
+// net for a host that suspects the engine, and the A/B partner of bench/reference_shapes.py.  The ONLY environment
+// variable this library reads.
 static bool use_engine() {
     static const bool v = [] {
         const char* e = std::getenv("RCFM_FFT");
@@ -285,6 +330,8 @@ static bool use_engine() {
 }
 
 struct rcfm_tuner_s {
+    Arena* arena = current_arena();   // rcfm_arena_bind at creation: every workspace of this handle, for its whole life
+    int opt_narrow = kNarrowDefault;  // RCFM_TUNER_OPT_NARROW_TILES (rcfm_pipeline_run passes the demodulator's setting)
     int64_t n = 0;
     int nch = 0;
     std::vector<int64_t> roll;   // normalised to [0, n)
@@ -294,6 +341,10 @@ struct rcfm_tuner_s {
     DeviceBuffer X;          // [halo | n bins | halo]: the halos repeat the far ends, so a channel's bins
     int64_t halo = 0;        //   base + d, |d| <= B/2 + 1, need no wrap-around (fused_passes.h)
     float2* ext = nullptr;   // rcfm_tuner_attach_spectrum: caller-owned storage of the same layout instead of X
+    // rcfm_tuner_attach_window: the caller's storage holds [halo | the window's bins | halo] only; `ext` is then the
+    // address bin -halo WOULD have (never dereferenced outside the window), and only the window's channels may run
+    bool ext_window = false;
+    int ext_first = 0, ext_count = 0;
     float2* spectrum() { return (ext ? ext : X.as<float2>()) + halo; }
     DeviceBuffer work;
     DeviceBuffer forward_work;                 // rocFFT fallback of the FORWARD transform: its own workspace -- load() may run on
@@ -377,7 +428,9 @@ struct rcfm_tuner_s {
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
         int64_t fb = 0, nb = 0;
         bin_window(first, count, &fb, &nb);
-        if (halo > 0) {
+        RC_REQUIRE(!ext_window || (first == ext_first && count == ext_count), RCFM_ERR_STATE,
+                   "the attached storage holds the window of another channel range (rcfm_tuner_attach_window)");
+        if (halo > 0 && !ext_window) {
             float2* Xs = spectrum();
             // segments of the window: [fb, min(fb + nb, n)) and, when it wraps, [0, fb + nb - n)
             const int64_t seg[2][2] = {{fb, std::min(fb + nb, n)}, {0, fb + nb > n ? fb + nb - n : 0}};
@@ -394,6 +447,14 @@ struct rcfm_tuner_s {
         loaded_windowed = nb < n;
         loaded_first = first;
         loaded_count = count;
+    }
+
+    // Can the bins of channels [first, first + count) live in a storage of their own, [halo | nbins | halo]?  Only a
+    // window that neither wraps around bin 0 nor touches the far ends (whose halos repeat the other end of the spectrum).
+    bool window_storage_ok(int first, int count, int64_t* fb, int64_t* nb) const {
+        if (halo <= 0 || count <= 0) return false;
+        bin_window(first, count, fb, nb);
+        return *nb < n && *fb >= halo && *fb + *nb <= n - halo;
     }
     struct Band {
         ResampleGeom geom;
@@ -434,12 +495,16 @@ struct rcfm_tuner_s {
     // outer line index, i.e. a TWO-pass plan (B <= 262144); three-pass bands keep contiguous phases.
     bool band_two_pass(int first) { return phase_capable(first) && band(bw[first]).engine->npass() == 2; }
 
-    void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr, int theta_pitch = 0) {
+    void run(int first, int count, float2* out, hipStream_t s, float* theta = nullptr, int theta_pitch = 0,
+             int narrow_mode = -1) {
+        if (narrow_mode < 0) narrow_mode = opt_narrow;
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= nch, RCFM_ERR_INDEX, "channel index out of range");
         RC_REQUIRE(loaded, RCFM_ERR_STATE, "rcfm_tuner_run called before rcfm_tuner_load");
         RC_REQUIRE(!loaded_windowed || (first >= loaded_first && first + count <= loaded_first + loaded_count),
                    RCFM_ERR_STATE,
                    "channel outside the shard the spectrum was loaded for (rcfm_tuner_shard, then rcfm_tuner_load)");
+        RC_REQUIRE(!ext_window || (first >= ext_first && first + count <= ext_first + ext_count), RCFM_ERR_STATE,
+                   "channel outside the window the attached storage holds (rcfm_tuner_attach_window)");
         if (count == 0) return;
         const int32_t B = bw[first];
         for (int i = 0; i < count; ++i)
@@ -452,7 +517,7 @@ struct rcfm_tuner_s {
             TunerGather tg{spectrum(), n, roll_dev.as<int64_t>() + first, 0.5, g.nyq, g.nneg, g.nyq_mode,
                            halo ? base_dev.as<int32_t>() + first : nullptr, halo};
             StageTimer tm(ST_TUNER_IFFT, s);
-            TILE_CALL(narrow_launch(*bd.engine, count), fused_tuner_ifft, *bd.engine, tg, out, band_tmp.as<float2>(), count, s,
+            TILE_CALL(narrow_launch(*bd.engine, count, narrow_mode), fused_tuner_ifft, *bd.engine, tg, out, band_tmp.as<float2>(), count, s,
                       theta, theta_pitch);
             return;
         }
@@ -473,12 +538,8 @@ struct rcfm_tuner_s {
     }
 };
 
-static bool env_default_on(const char* name) {
-    const char* e = std::getenv(name);
-    return !(e && e[0] == '0');
-}
-
 struct rcfm_demod_s {
+    Arena* arena = current_arena();   // rcfm_arena_bind at creation
     int kind = 0, C = 0, B = 0, A = 0, ch = 1, chunk = 1;
     double tau = 75e-6;
     float taps_h[51];
@@ -520,13 +581,15 @@ struct rcfm_demod_s {
     std::unique_ptr<FftEngine> eng_Ad;         // length A as (A / n_1, n_1): its first pass tiles like eng_B's last
     std::unique_ptr<FftEngine> eng_Bi;         // eng_B's two pass lengths swapped (k_fft_tile2 pairing)
     DeviceBuffer buf_Ti;
-    // rcfm_demod_set_option: which forms of the chain rcfm_pipeline_run / run_chunk may use.  The defaults come from
-    // the RCFM_* environment switches (A/B tooling, read once per process); parity tests flip them per handle to get a
-    // second evaluation that shares no kernel schedule with the default one.
-    bool opt_lds_chain = env_default_on("RCFM_LDS_CHAIN");
-    bool opt_fused_tiles = env_default_on("RCFM_PILOT_CHAIN") && env_default_on("RCFM_DECIM_TILE");
-    bool opt_phase_link = env_default_on("RCFM_PHASE_LINK");
-    int opt_narrow = narrow_default();   // RCFM_OPT_NARROW_TILES
+    // rcfm_demod_set_option: which forms of the chain rcfm_pipeline_run / run_chunk may use (all on by default).  Parity
+    // tests flip them per handle to get a second evaluation that shares no kernel schedule with the default one; the
+    // A/B tools isolate one fusion at a time (RCFM_OPT_PILOT_CHAIN / RCFM_OPT_DECIM_TILE; RCFM_OPT_FUSED_TILES sets both).
+    bool opt_lds_chain = true;
+    bool opt_pilot_chain = true;     // pilot chain, Hilbert pair / packed tiles (two transforms per tile around the mask)
+    bool opt_decim_tile = true;      // spectral decimation between FFT_B's last pass and IFFT_A's first
+    bool opt_phase_link = true;
+    bool opt_lds_deemph = true;      // MFM's de-emphasis inside the LDS chain
+    int opt_narrow = kNarrowDefault;   // RCFM_OPT_NARROW_TILES
     bool narrow(int cnt) const { return eng_B && narrow_launch(*eng_B, cnt, opt_narrow); }
     DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2, buf_dc;
     int tiles = 0;
@@ -557,7 +620,7 @@ struct rcfm_demod_s {
             // A = n_1 L2 with L2 even (k_fft_tile2_decim); if the planner's order of the two factors does not allow that
             // and the other order does (256 000 -> 32 000: 512 x 500 gives L2 = 62.5, 500 x 512 gives 64), take the other
             // one -- the fused chain uses both orders of the plan anyway (eng_Bi below).
-            if (eng_B->npass() == 2 && A < B && !std::getenv("RCFM_FFT_FORCE")) {
+            if (eng_B->npass() == 2 && A < B) {
                 const FftPlanDesc& pd = eng_B->desc();
                 auto decim_ok = [&](const FftEngine& eb) {
                     const int64_t n1 = eb.desc().pass[0].L;
@@ -581,8 +644,7 @@ struct rcfm_demod_s {
             if (kind == RCFM_WBFM) {
                 buf_U2.reset(((c + 1) / 2) * B * sizeof(float2));
                 const FftPlanDesc& pd = eng_B->desc();
-                const char* off = std::getenv("RCFM_NO_TILE2");
-                if (pd.npass == 2 && !(off && off[0] == '1')) {
+                if (pd.npass == 2) {
                     const int64_t swapped[2] = {pd.pass[1].L, pd.pass[0].L};
                     eng_Bi = std::make_unique<FftEngine>(B, swapped, 2);
                     buf_Ti.reset(c * eng_Bi->tmp_stride() * sizeof(float2));
@@ -621,11 +683,7 @@ struct rcfm_demod_s {
     // Row pitch (samples) of the packed audio between IFFT_A's last pass and the de-emphasis kernel: rows of n_1
     // samples padded to whole 128-byte lines; 0 = contiguous.
     int audio_pitch() const {
-        static const bool off = [] {
-            const char* e = std::getenv("RCFM_AUDIO_PITCH");   // =0: contiguous rows (A/B runs)
-            return e && e[0] == '0';
-        }();
-        if (off || !eng_Ad || kind != RCFM_WBFM || !deemph_fused()) return 0;
+        if (!eng_Ad || kind != RCFM_WBFM || !deemph_fused()) return 0;
         const int64_t n1 = eng_Ad->row_length();
         return (n1 % 16 == 0 || (n1 * 2) % 4 != 0) ? 0 : (int)((n1 + 15) / 16 * 16);
     }
@@ -724,12 +782,9 @@ struct rcfm_demod_s {
                 float2* T = buf_T.as<float2>();
                 float2* TA = buf_TA.as<float2>();
                 float2* U2 = buf_U2.as<float2>();
-                // RCFM_PILOT_CHAIN=0: pair FFT -> U2 -> masked IFFT as separate transforms; RCFM_HILBERT_UNPACK=1:
-                // additionally one inverse FFT per channel (A/B testing of the fused forms)
-                static const bool unpacked = std::getenv("RCFM_HILBERT_UNPACK") != nullptr;
-                const bool no_chain = !opt_fused_tiles;
-                const bool chain = eng_Bi && !unpacked && !no_chain && TILE_CALL(nw, fused_pilot_chain_applies, *eng_B, *eng_Bi, cnt);
-                const bool packed = eng_Bi && opt_fused_tiles && !unpacked && TILE_CALL(nw, fused_hilbert_packed_applies, *eng_Bi, *eng_B, cnt);
+                // RCFM_OPT_PILOT_CHAIN = 0: pair FFT -> U2 -> masked IFFT as separate transforms
+                const bool chain = eng_Bi && opt_pilot_chain && TILE_CALL(nw, fused_pilot_chain_applies, *eng_B, *eng_Bi, cnt);
+                const bool packed = eng_Bi && opt_pilot_chain && TILE_CALL(nw, fused_hilbert_packed_applies, *eng_Bi, *eng_B, cnt);
                 bool paired = false;
                 if (chain) {
                     {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
@@ -746,7 +801,7 @@ struct rcfm_demod_s {
                         StageTimer tm(ST_FFT_REAL_B, s);
                         TILE_CALL(nw, fused_real_pair_fft, *eng_B, p, U2, T, cnt, packed ? kKeepLowerHalf : -1, s);
                     }
-                    if (eng_Bi && opt_fused_tiles) {
+                    if (eng_Bi && opt_pilot_chain) {
                         // one-sided mask -> inverse FFT -> stereo matrix -> first pass of the packed L/R FFT:
                         // the last IFFT pass and the first FFT pass share their tiles (fused_passes.h)
                         StageTimer tm(ST_IFFT_B, s);
@@ -755,7 +810,7 @@ struct rcfm_demod_s {
                                                                              buf_Ti.as<float2>(), T, cnt, s);
                     }
                 }
-                const bool no_decim = !opt_fused_tiles;
+                const bool no_decim = !opt_decim_tile;
                 if (paired && eng_Ad && !no_decim && TILE_CALL(nw, fused_fft_decim_ifft_applies, *eng_B, *eng_Ad, cnt)) {
                     const int pitch = audio_pitch();
                     {   // packed L/R FFT last pass -> decimation -> IFFT_A: the B-point spectrum stays on chip
@@ -846,7 +901,7 @@ struct rcfm_demod_s {
             StageTimer tm(ST_DISC, s);
             launch_discriminator(iq, d, B, cnt, s);
         }
-        const bool no_decim_pairs = !opt_fused_tiles;
+        const bool no_decim_pairs = !opt_decim_tile;
         if (eng_B && eng_Ad && !no_decim_pairs && ((int64_t)A % 4 == 0 || kind == RCFM_FM) &&
             TILE_CALL(nw, fused_fft_decim_ifft_applies, *eng_B, *eng_Ad, (cnt + 1) / 2)) {
             // two channels per complex signal from the pair FFT through the decimation to the inverse FFT:
@@ -1097,6 +1152,53 @@ int rcfm_stream_destroy(void* stream) {
     });
 }
 
+// ---- placement -----------------------------------------------------------------
+
+int rcfm_arena_create(size_t block_bytes, rcfm_arena_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out != nullptr, RCFM_ERR_ARG, "out is NULL");
+        auto a = std::make_unique<Arena>();
+        a->block_bytes = block_bytes ? block_bytes : ((size_t)1 << 30);
+        if (block_bytes) {   // the first block now: its placement is the draw the caller asked for
+            void* base = nullptr;
+            RC_HIP(hipMalloc(&base, a->block_bytes));
+            a->blocks.push_back(Arena::Block{static_cast<char*>(base), a->block_bytes, 0});
+        }
+        *out = a.release();
+    });
+}
+
+int rcfm_arena_bind(rcfm_arena_t a) {
+    return guarded([&] { g_arena = a; });
+}
+
+int rcfm_arena_stats(rcfm_arena_t a, size_t* reserved_bytes, size_t* used_bytes, size_t* live_pieces) {
+    return guarded([&] {
+        RC_REQUIRE(a != nullptr, RCFM_ERR_ARG, "NULL arena");
+        std::lock_guard<std::mutex> lock(a->mu);
+        size_t r = 0, u = 0;
+        for (auto& b : a->blocks) {
+            r += b.bytes;
+            u += b.used;
+        }
+        if (reserved_bytes) *reserved_bytes = r;
+        if (used_bytes) *used_bytes = u;
+        if (live_pieces) *live_pieces = a->live;
+    });
+}
+
+int rcfm_arena_destroy(rcfm_arena_t a) {
+    return guarded([&] {
+        if (!a) return;
+        {
+            std::lock_guard<std::mutex> lock(a->mu);
+            RC_REQUIRE(a->live == 0, RCFM_ERR_STATE, "handles created inside this arena are still alive: destroy them first");
+        }
+        if (g_arena == a) g_arena = nullptr;
+        delete a;
+    });
+}
+
 // ---- tuner -----------------------------------------------------------------
 
 int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_t* bw_host, rcfm_tuner_t* out) {
@@ -1144,6 +1246,9 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
 int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
     return guarded([&] {
         RC_REQUIRE(t && x, RCFM_ERR_ARG, "NULL argument");
+        ArenaScope scope(t->arena);
+        RC_REQUIRE(!t->ext_window, RCFM_ERR_STATE,
+                   "rcfm_tuner_load needs storage for the whole spectrum: a window is attached (rcfm_tuner_attach_window)");
         {
             StageTimer tm(ST_TUNER_FFT, as_stream(stream));
             bool halo_done = false;
@@ -1183,6 +1288,7 @@ int rcfm_tuner_shard(rcfm_tuner_t t, int first, int count) {
 int rcfm_tuner_run(rcfm_tuner_t t, int first, int count, void* out, void* stream) {
     return guarded([&] {
         RC_REQUIRE(t && out, RCFM_ERR_ARG, "NULL argument");
+        ArenaScope scope(t->arena);
         t->run(first, count, static_cast<float2*>(out), as_stream(stream));
     });
 }
@@ -1190,6 +1296,7 @@ int rcfm_tuner_run(rcfm_tuner_t t, int first, int count, void* out, void* stream
 int rcfm_tuner_spectrum(rcfm_tuner_t t, void** X) {
     return guarded([&] {
         RC_REQUIRE(t && X, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(!t->ext_window, RCFM_ERR_STATE, "a window is attached: the whole spectrum is not on this device");
         *X = t->spectrum();
     });
 }
@@ -1207,7 +1314,9 @@ int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, 
         RC_REQUIRE(t != nullptr, RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(loaded_count <= 0 || (loaded_first >= 0 && loaded_first + loaded_count <= t->nch), RCFM_ERR_INDEX,
                    "channel index out of range");
+        ArenaScope scope(t->arena);
         t->ext = static_cast<float2*>(storage);
+        t->ext_window = false;
         // the handle's own [halo | n | halo] buffer is not needed while the caller supplies the storage
         const size_t own_bytes = sizeof(float2) * (size_t)(t->n + 2 * t->halo);
         if (storage != nullptr) t->X.reset(0);
@@ -1219,6 +1328,51 @@ int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, 
         t->loaded_windowed = t->loaded && nb < t->n;
         t->loaded_first = loaded_first;
         t->loaded_count = std::max(loaded_count, 0);
+    });
+}
+
+int rcfm_tuner_window_layout(rcfm_tuner_t t, int first, int count, int64_t* halo, int64_t* nbins) {
+    return guarded([&] {
+        RC_REQUIRE(t && halo && nbins, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= t->nch, RCFM_ERR_INDEX, "channel index out of range");
+        int64_t fb = 0, nb = 0;
+        RC_REQUIRE(t->window_storage_ok(first, count, &fb, &nb), RCFM_ERR_SIZE,
+                   "these channels' bins wrap around the ends of the spectrum (or are all of it): no window storage");
+        *halo = t->halo;
+        *nbins = nb;
+    });
+}
+
+int rcfm_tuner_attach_window(rcfm_tuner_t t, void* storage, int first, int count) {
+    return guarded([&] {
+        RC_REQUIRE(t && storage, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(first >= 0 && count >= 0 && first + count <= t->nch, RCFM_ERR_INDEX, "channel index out of range");
+        int64_t fb = 0, nb = 0;
+        RC_REQUIRE(t->window_storage_ok(first, count, &fb, &nb), RCFM_ERR_SIZE,
+                   "these channels' bins wrap around the ends of the spectrum (or are all of it): no window storage");
+        t->X.reset(0);
+        // bin b of the window sits at storage[halo + b - fb]: `ext` is where bin -halo would be
+        t->ext = static_cast<float2*>(storage) - fb;
+        t->ext_window = true;
+        t->ext_first = first;
+        t->ext_count = count;
+        t->loaded = false;
+        t->loaded_windowed = false;
+        t->loaded_first = first;
+        t->loaded_count = 0;
+    });
+}
+
+int rcfm_tuner_set_option(rcfm_tuner_t t, int option, int value) {
+    return guarded([&] {
+        RC_REQUIRE(t, RCFM_ERR_ARG, "NULL handle");
+        switch (option) {
+            case RCFM_TUNER_OPT_NARROW_TILES:
+                RC_REQUIRE(value >= 0 && value <= 2, RCFM_ERR_ARG, "narrow tiles: 0 never, 1 automatic, 2 always");
+                t->opt_narrow = value;
+                break;
+            default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown tuner option");
+        }
     });
 }
 
@@ -1261,10 +1415,7 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
             // workgroups: 1024 channels of 240 kHz per launch (9.8 GB of workspace) are 1.3 % faster than 512.
             // Narrow channels take proportionally more per launch (the same workspace): cfg5 (B = 12 500) measured
             // 2.23 / 2.10 / 2.06 / 2.05 ms at 1024 / 2048 / 4096 / 8192 channels per launch.
-            const char* e = std::getenv("RCFM_CHUNK");
-            const int dflt = (int)std::min<int64_t>(8192, std::max<int64_t>(1024, (int64_t)1024 * 240000 / B));
-            chunk = e ? std::atoi(e) : dflt;
-            if (chunk <= 0) chunk = dflt;
+            chunk = (int)std::min<int64_t>(8192, std::max<int64_t>(1024, (int64_t)1024 * 240000 / B));
         }
         d->chunk = std::min(chunk, C);
         d->geom.build(B, A, 0.54 /* hamm */, false);
@@ -1297,6 +1448,7 @@ int rcfm_demod_run(rcfm_demod_t d, int first, int count, const void* iq, void* a
     return guarded([&] {
         RC_REQUIRE(d && iq && audio, RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= d->C, RCFM_ERR_INDEX, "channel index out of range");
+        ArenaScope scope(d->arena);
         const float2* in = static_cast<const float2*>(iq);
         float* outp = static_cast<float*>(audio);
         for (int off = 0; off < count; off += d->chunk) {
@@ -1361,7 +1513,10 @@ int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
         RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");
         switch (option) {
             case RCFM_OPT_LDS_CHAIN: d->opt_lds_chain = value != 0; break;
-            case RCFM_OPT_FUSED_TILES: d->opt_fused_tiles = value != 0; break;
+            case RCFM_OPT_FUSED_TILES: d->opt_pilot_chain = d->opt_decim_tile = value != 0; break;
+            case RCFM_OPT_PILOT_CHAIN: d->opt_pilot_chain = value != 0; break;
+            case RCFM_OPT_DECIM_TILE: d->opt_decim_tile = value != 0; break;
+            case RCFM_OPT_LDS_DEEMPH: d->opt_lds_deemph = value != 0; break;
             case RCFM_OPT_PHASE_LINK: d->opt_phase_link = value != 0; break;
             case RCFM_OPT_NARROW_TILES:
                 RC_REQUIRE(value >= 0 && value <= 2, RCFM_ERR_ARG, "narrow tiles: 0 never, 1 automatic, 2 always");
@@ -1396,6 +1551,7 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
         RC_REQUIRE(t && d && audio, RCFM_ERR_ARG, "NULL argument");
         RC_REQUIRE(first >= 0 && count >= 0 && first + count <= t->nch && first + count <= d->C, RCFM_ERR_INDEX,
                    "channel index out of range");
+        ArenaScope scope(d->arena);
         d->buf_iq.reserve((size_t)d->chunk * d->B * sizeof(float2));
         float* outp = static_cast<float*>(audio);
         for (int off = 0; off < count; off += d->chunk) {
@@ -1403,7 +1559,7 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
             RC_REQUIRE(t->bw[first + off] == d->B, RCFM_ERR_SIZE, "input_sig size and input_size mismatch");
             // Narrow FM / MFM channels whose whole chain fits the LDS of a CU: gather, IFFT_B, discriminator, FFT_B,
             // decimation and IFFT_A of a channel pair in ONE kernel (lds_chain.h); only the audio reaches memory.
-            // RCFM_LDS_CHAIN=0: the multi-pass launches (A/B runs).
+            // RCFM_OPT_LDS_CHAIN = 0: the multi-pass launches.
             const bool no_lds = !d->opt_lds_chain;
             if (!no_lds && d->kind != RCFM_WBFM && lds_chain_supported(d->B, d->A) && t->fast_gather_ok(first + off)) {
                 RC_REQUIRE(t->loaded, RCFM_ERR_STATE, "rcfm_pipeline_run called before rcfm_tuner_load");
@@ -1418,8 +1574,7 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                 // MFM: de-emphasis, mean removal and clip (mfm.py:62-66) run inside the same kernel when the taps are the
                 // one-pole response deemphasis.py:37-46 designs (always, unless a caller replaced them): only the audio
                 // leaves the chip.  Otherwise the chain stops at the decimated signal and the de-emphasis launches follow.
-                static const bool deemph_chain = env_default_on("RCFM_LDS_DEEMPH");   // =0: the de-emphasis launches (A/B runs)
-                const bool deemph_on_chip = d->kind == RCFM_MFM && deemph_chain && d->deemph_geometric() &&
+                const bool deemph_on_chip = d->kind == RCFM_MFM && d->opt_lds_deemph && d->deemph_geometric() &&
                                             lds_chain_deemph_supported(d->B, d->A);
                 float* dst = (d->kind == RCFM_FM || deemph_on_chip) ? out_c : d->buf_v.as<float>();
                 LdsChainArgs a{t->spectrum(), t->base_dev.as<int32_t>() + first + off, t->n, tg.nyq,
@@ -1443,7 +1598,7 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
             }
             // Every demodulator starts with the FM discriminator, which only needs the samples' phases:
             // the tuner's last pass leaves angle(x) / pi (float32) instead of x (complex64) -- half the
-            // bytes written here and read back by the first demod kernel.  RCFM_PHASE_LINK=0: complex hand-over.
+            // bytes written here and read back by the first demod kernel.  RCFM_OPT_PHASE_LINK = 0: complex hand-over.
             const bool no_phase = !d->opt_phase_link;
             if (!no_phase && d->phase_capable() && t->phase_capable(first + off)) {
                 // FM / MFM read the phases through LoadPhaseStepPair, which understands padded rows: when the tuner's
@@ -1451,22 +1606,24 @@ int rcfm_pipeline_run(rcfm_tuner_t t, rcfm_demod_t d, int first, int count, void
                 // the rows go to a pitch of whole 128-byte lines.  (WBFM's pilot stage reads contiguous phases.)
                 PhaseRows rows;
                 const int n1 = t->band_row_length(first + off);
-                static const bool no_pad = [] {
-                    const char* e = std::getenv("RCFM_PHASE_PITCH");
-                    return e && e[0] == '0';
-                }();
-                if (!no_pad && d->kind != RCFM_WBFM && d->eng_B && t->band_two_pass(first + off) && n1 > 0 &&
+                if (d->kind != RCFM_WBFM && d->eng_B && t->band_two_pass(first + off) && n1 > 0 &&
                     n1 % 16 != 0 && d->B % n1 == 0 && d->B < (1 << 20) && n1 < (1 << 12)) {
                     rows.row = n1;
                     rows.pitch = (n1 + 15) / 16 * 16;     // floats: a 64-byte store segment never straddles a line
                     d->buf_iq.reserve((size_t)d->chunk * rows.channel_stride(d->B) * sizeof(float));
                 }
                 float* theta = d->buf_iq.as<float>();
-                t->run(first + off, cnt, nullptr, as_stream(stream), theta, rows.pitch);
+                {
+                    ArenaScope ts(t->arena);
+                    t->run(first + off, cnt, nullptr, as_stream(stream), theta, rows.pitch, d->opt_narrow);
+                }
                 d->run_chunk(first + off, cnt, nullptr, outp + (size_t)off * d->A * d->ch, as_stream(stream), theta, rows);
                 continue;
             }
-            t->run(first + off, cnt, d->buf_iq.as<float2>(), as_stream(stream));
+            {
+                ArenaScope ts(t->arena);
+                t->run(first + off, cnt, d->buf_iq.as<float2>(), as_stream(stream), nullptr, 0, d->opt_narrow);
+            }
             d->run_chunk(first + off, cnt, d->buf_iq.as<float2>(), outp + (size_t)off * d->A * d->ch,
                          as_stream(stream));
         }
@@ -1889,6 +2046,24 @@ int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, v
         std::lock_guard<std::mutex> lock(mu);
         auto it = engines.find(n);
         if (it == engines.end()) it = engines.emplace(n, std::make_unique<FftEngine>(n)).first;
+        tmp.reserve((size_t)batch * it->second->tmp_stride() * sizeof(float2));
+        it->second->c2c(static_cast<const float2*>(in), static_cast<float2*>(out), tmp.as<float2>(), batch,
+                        inverse != 0, 1.0f, as_stream(stream));
+    });
+}
+
+int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int batch, int inverse, const void* in, void* out,
+                      void* stream) {
+    return guarded([&] {
+        RC_REQUIRE(in && out && batch >= 1 && pass_lengths && npass >= 1 && npass <= kFftMaxPasses, RCFM_ERR_ARG, "bad argument");
+        static std::mutex mu;
+        static std::map<std::vector<int64_t>, std::unique_ptr<FftEngine>> engines;
+        static DeviceBuffer tmp;
+        std::lock_guard<std::mutex> lock(mu);
+        std::vector<int64_t> key(pass_lengths, pass_lengths + npass);
+        auto it = engines.find(key);
+        if (it == engines.end()) it = engines.emplace(key, std::make_unique<FftEngine>(n, pass_lengths, npass)).first;
+        RC_REQUIRE(it->second->desc().n == n, RCFM_ERR_ARG, "the pass lengths do not multiply to n");
         tmp.reserve((size_t)batch * it->second->tmp_stride() * sizeof(float2));
         it->second->c2c(static_cast<const float2*>(in), static_cast<float2*>(out), tmp.as<float2>(), batch,
                         inverse != 0, 1.0f, as_stream(stream));

@@ -50,6 +50,24 @@ int guarded(F&& body) {
     }
 }
 
+// ---- placement control (rcfm_arena_*, include/rcfm.h) ----------------------------------------------------------
+// Where hipMalloc puts a workspace moves the kernels that stream through it by several per cent
+// (profiles/r04_k_placement.md).  A caller who wants ONE draw for a whole handle set creates an arena -- a few large
+// device blocks, bump-allocated -- and binds it while the handles are created; every workspace of those handles of
+// kArenaMinBytes or more then comes from the arena, for the handles' whole life (lazy growth included).
+using Arena = ::rcfm_arena_s;
+constexpr size_t kArenaMinBytes = (size_t)1 << 20;
+Arena* current_arena();                         // thread-local: the arena allocations of this thread draw from (or null)
+void* arena_take(Arena* a, size_t bytes);       // a piece of the arena (never null: the arena grows by whole blocks)
+void arena_drop(Arena* a);                      // a piece is no longer used (the bytes return when the arena goes)
+struct ArenaScope {                             // entry points of a handle run inside its arena
+    Arena* prev;
+    explicit ArenaScope(Arena* a);
+    ~ArenaScope();
+    ArenaScope(const ArenaScope&) = delete;
+    ArenaScope& operator=(const ArenaScope&) = delete;
+};
+
 // Owning device allocation (handles own their workspaces; freed on destroy).
 class DeviceBuffer {
    public:
@@ -57,14 +75,20 @@ class DeviceBuffer {
     explicit DeviceBuffer(size_t bytes) { reset(bytes); }
     DeviceBuffer(const DeviceBuffer&) = delete;
     DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-    DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), bytes_(o.bytes_), arena_(o.arena_) {
+        o.p_ = nullptr;
+        o.bytes_ = 0;
+        o.arena_ = nullptr;
+    }
     DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
         if (this != &o) {
             release();
             p_ = o.p_;
             bytes_ = o.bytes_;
+            arena_ = o.arena_;
             o.p_ = nullptr;
             o.bytes_ = 0;
+            o.arena_ = nullptr;
         }
         return *this;
     }
@@ -72,7 +96,13 @@ class DeviceBuffer {
     void reset(size_t bytes) {
         release();
         if (bytes) {
-            RC_HIP(hipMalloc(&p_, bytes));
+            Arena* a = bytes >= kArenaMinBytes ? current_arena() : nullptr;
+            if (a) {
+                p_ = arena_take(a, bytes);
+                arena_ = a;
+            } else {
+                RC_HIP(hipMalloc(&p_, bytes));
+            }
             bytes_ = bytes;
         }
     }
@@ -93,12 +123,15 @@ class DeviceBuffer {
 
    private:
     void release() {
-        if (p_) (void)hipFree(p_);
+        if (p_ && arena_) arena_drop(arena_);
+        else if (p_) (void)hipFree(p_);
         p_ = nullptr;
         bytes_ = 0;
+        arena_ = nullptr;
     }
     void* p_ = nullptr;
     size_t bytes_ = 0;
+    Arena* arena_ = nullptr;
 };
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }

@@ -55,7 +55,7 @@ __device__ __forceinline__ void stage_rt(float2* tile, const float2* tw, int L2,
         float2 v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<true>(base + q * m, w)];
-        dft_pa<R>(v);
+        dft_p<R>(v);
         const int ts = kp * step;
 #pragma unroll
         for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], tw[q * ts]);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_de
         if ((rowsL % RG == 0) || g < rowsL) {
 #pragma unroll
             for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_pa<RL>(&xr[it * RL]);
+            dft_p<RL>(&xr[it * RL]);
         }
     }
     lds_barrier();   // every slot has been read
@@ -255,7 +255,7 @@ inline bool fft_tile2_decim_rt_applies(const FftPassDev& d1, const FftPassDev& d
     if (!have || !RCFM_FFT_TWO_STAGE || (L2 & 1) || L2 < 16 || L2 >= d1.p.L) return false;
     for (int s = 0; s < d2.p.nstages; ++s)
         if (!decim_rt_radix_ok(d2.p.radix[s])) return false;
-    return !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l && d1.p.n_inner == d2.p.n_inner &&
+    return d1.p.load_along_l && !d2.p.load_along_l && d1.p.n_inner == d2.p.n_inner &&
            d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 && d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 &&
            d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
 }

@@ -75,7 +75,6 @@ struct FftPassDev {
     float fine_step;          // 2 pi / n
     int fine_bits;
     int64_t in_batch, out_batch;
-    int debug;                // RCFM_FFT_DEBUG bit mask: timing experiments only (wrong results)
 };
 
 // Rows of the transform's output to keep (row r = output elements [r n_1, (r+1) n_1), n_1 = the plan's first

@@ -135,14 +135,7 @@ bool split(int64_t n, int np, int max_l, int64_t* f, double* best_cost = nullptr
     return ok;
 }
 
-// RCFM_FFT_BIG=0 keeps every plan on <= 512-point tiles (A/B testing).
-bool big_tiles_enabled() {
-    static const bool v = [] {
-        const char* e = std::getenv("RCFM_FFT_BIG");
-        return !(e && e[0] == '0') && !fftk::getenv_generic_fft();   // the generic kernel stops at kFftMaxL
-    }();
-    return v;
-}
+constexpr bool big_tiles_enabled() { return true; }
 
 }  // namespace
 
@@ -275,22 +268,6 @@ int FftEngine::compute_units() {
 }
 
 FftEngine::FftEngine(int64_t n) {
-    // RCFM_FFT_FORCE="f1,f2,..." (product n): pass lengths for plan experiments
-    if (const char* e = std::getenv("RCFM_FFT_FORCE")) {
-        int64_t f[kFftMaxPasses], prod = 1;
-        int nf = 0;
-        for (const char* c = e; *c && nf < kFftMaxPasses;) {
-            char* end = nullptr;
-            f[nf] = std::strtoll(c, &end, 10);
-            if (end == c) break;
-            prod *= f[nf++];
-            c = (*end == ',') ? end + 1 : end;
-        }
-        if (prod == n && fft_plan_describe(n, &desc_, 0, f, nf)) {
-            build_tables();
-            return;
-        }
-    }
     RC_REQUIRE(fft_plan_describe(n, &desc_), RCFM_ERR_ARG, "length not supported by the FFT engine");
     build_tables();
 }
@@ -345,20 +322,7 @@ FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch) const
     d.fine_bits = desc_.fine_bits;
     d.in_batch = in_batch;
     d.out_batch = out_batch;
-    static const int dbg = [] {
-        const char* e = std::getenv("RCFM_FFT_DEBUG");
-        return e ? std::atoi(e) : 0;
-    }();
-    d.debug = dbg;
     return d;
-}
-
-static bool ping_pong_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("RCFM_FFT_PINGPONG");   // =0: middle passes in place (A/B runs)
-        return !(e && e[0] == '0');
-    }();
-    return on;
 }
 
 void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
@@ -376,7 +340,7 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
     // transforms keep the in-place middle passes: N = 1e7 (80 MB) lost 3.6 % with twice the footprint.  When out aliases
     // in or tmp the old routing stays.
     const bool ping_pong = np >= 3 && ts == n && in != out && out != tmp && in != tmp &&
-                           (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20) && ping_pong_enabled();
+                           (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20);
     auto mid = [&](int t) -> float2* {   // where pass t < np - 1 writes
         if (!ping_pong) return tmp;
         return ((np - 2 - t) & 1) ? out : tmp;

@@ -322,15 +322,6 @@ __device__ __forceinline__ float2 big_twiddle(const FftPassDev& d, unsigned e) {
     return cmul(c, make_float2(co, -s));
 }
 
-// RCFM_FFT_GENERIC=1 forces the runtime-radix kernel (A/B testing).
-inline bool getenv_generic_fft() {
-    static const bool v = [] {
-        const char* e = std::getenv("RCFM_FFT_GENERIC");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
-
 struct LineId {
     int batch;
     int64_t o1, o2, i;
@@ -500,18 +491,12 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
 struct BlockPos {
     unsigned tile, batch;
 };
-// A workgroup's place in the launch: the hardware's blockIdx / gridDim, or -- persistent kernels -- the place a
-// virtual workgroup id would have had in the equivalent one-tile-per-workgroup launch (same linear order, so the
-// same XCD: the persistent grid is a multiple of 8 and workgroup b only ever takes ids = b mod 8).
+// A workgroup's place in the launch (blockIdx / gridDim).
 struct VBlock {
     unsigned x, y, z, gx, gy, gz;
 };
 __device__ __forceinline__ VBlock vblock_hw() {
     return VBlock{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z};
-}
-__device__ __forceinline__ VBlock vblock_of(unsigned id, unsigned gx, unsigned gy, unsigned gz) {
-    const unsigned x = id % gx, r = id / gx;
-    return VBlock{x, r % gy, r / gy, gx, gy, gz};
 }
 __device__ __forceinline__ BlockPos block_pos(const VBlock& vb);
 __device__ __forceinline__ BlockPos block_pos() { return block_pos(vblock_hw()); }
@@ -591,16 +576,6 @@ __device__ __forceinline__ void dft_p(float2* v) {
     if constexpr (R > 10 || R == 7 || R == 9) dft_nat<R>(v);
 }
 
-// RCFM_ABLATE (timing experiments only, wrong results): 1 = no inter-pass twiddle, 2 = no stage twiddles, 4 = no
-// butterflies (any kernel), 8 = no arctangent in StorePhase, 16 = no taps in the pilot stage's FIR.
-#ifndef RCFM_ABLATE
-#define RCFM_ABLATE 0
-#endif
-template <int R>
-__device__ __forceinline__ void dft_pa(float2* v) {
-    if constexpr (!(RCFM_ABLATE & 4)) dft_p<R>(v);
-}
-
 // RCFM_FFT_ROWS_PITCH17 (default): rows-type tiles use a padded pitch of 17 points instead of the XOR
 // swizzle: constant LDS offsets instead of integer work per access; the transposing store stays
 // conflict-free (34-dword stride), 32-lane reads pay one extra LDS cycle.  Measured +1.4 % on cfg4
@@ -648,9 +623,8 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
             if constexpr (GTW) pw[0] = tw[kp * step];   // issued ahead of the LDS reads it will meet
 #pragma unroll
             for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<SWZ, P17>(base + q * m, w)];
-            dft_pa<R>(v);
-            if constexpr (RCFM_ABLATE & 2) {
-            } else if constexpr (GTW) {
+            dft_p<R>(v);
+            if constexpr (GTW) {
                 twiddle_powers<R>(pw[0], pw);
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[dft_slot<R>(q)] = cmul(v[dft_slot<R>(q)], pw[q]);
@@ -686,12 +660,9 @@ constexpr bool triple_tile(int L) { return RCFM_FFT_TRIPLE400 && L == 400; }
 //                   (tile_base is workgroup-uniform, off a 32-bit per-lane offset) and does NO
 //                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
 // StoreOp contract: operator()(id, k, tile_base, off, v).
-// PERSIST: the grid is two workgroups per CU and each walks tiles id = blockIdx.x, + gridDim.x, ... of the virtual grid
-// `vgrid` (RCFM_FFT_PERSIST): no workgroup dispatch between the tiles of a CU, the next tile's loads are issued right
-// behind the stores of the previous one.
-template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp, bool PERSIST = false>
+template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
 __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
-                                                                                          StoreOp store, dim3 vgrid) {
+                                                                                          StoreOp store) {
     // BIG: two 1024-thread workgroups per CU -- the tile is the whole LDS budget of the workgroup (80 KiB), so the
     // stage twiddles come from the table in global memory (twiddle_powers) and rows tiles use the XOR swizzle.
     constexpr bool BIG = big_tile_pair(L) || triple_tile(L);
@@ -706,15 +677,10 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
     __shared__ __attribute__((aligned(16))) float2 tw_lds[BIG ? 1 : L];
     const float2* tw = BIG ? d.stage_tw : tw_lds;
     const FftPass& p = d.p;
-    static_assert(!PERSIST || BIG, "persistent form: big tiles only (no stage-twiddle table in LDS to refill)");
 
-    const unsigned vtotal = PERSIST ? vgrid.x * vgrid.y * vgrid.z : 1u;
-#pragma unroll 1
-    for (unsigned vid = PERSIST ? blockIdx.x : 0u; vid < vtotal; vid += PERSIST ? gridDim.x : 1u) {
-    int tid = threadIdx.x;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tid));   // per-thread index tables (e / L, e % L per load) stay in the loop
+    const int tid = threadIdx.x;
     const int w = tid & (W - 1), rg = tid >> kLogW;
-    const VBlock vb = PERSIST ? vblock_of(vid, vgrid.x, vgrid.y, vgrid.z) : vblock_hw();
+    const VBlock vb = vblock_hw();
     LineId id;
     const BlockPos bp = block_pos(vb);
     id.batch = bp.batch;
@@ -728,13 +694,7 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + (int64_t)i0 * p.in_i;
     const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0;
-    unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
-    if constexpr (PERSIST) {
-        // the strides are loop-invariant, and hoisting every multiple of them out of the tile loop (10 .. 20 row
-        // offsets per thread) costs more registers than the 64 a two-workgroups-per-CU kernel has: keep the
-        // address arithmetic inside the iteration
-        asm volatile("" : "+s"(in_l), "+s"(in_i), "+s"(out_k));
-    }
+    const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
 
     // ---- global loads: all issued before anything waits -----------------------------------
     constexpr int NF = fetch_count<LoadOp>::value;
@@ -865,9 +825,8 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
                     else if constexpr (CTX) x[q] = load.post(id, b + q * m0, x[q], ctx);
                     else x[q] = load.post(id, b + q * m0, x[q]);
                 }
-                dft_pa<R0>(x);
-                if constexpr (RCFM_ABLATE & 2) {
-                } else if constexpr (BIG) {
+                dft_p<R0>(x);
+                if constexpr (BIG) {
                     float2 pw[R0];
                     twiddle_powers<R0>(tw[b], pw);
 #pragma unroll
@@ -898,7 +857,7 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
     // then successive powers of D = W_n^(f L / RL) (RL - 1 <= 9 multiplications).
     const unsigned f = (unsigned)(id.o1 * p.tw_o1 + id.o2 * p.tw_o2 + (int64_t)(i0 + w) * p.tw_i);
     float2 D = make_float2(1.f, 0.f);
-    constexpr bool PTW = !ROWS && !(RCFM_ABLATE & 1);
+    constexpr bool PTW = !ROWS;
     if constexpr (PTW) D = big_twiddle(d, f * (unsigned)(L / RL));
     id.i = i0 + w;
     const bool lane_ok = w < wvalid;
@@ -909,7 +868,7 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
             float2 x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<ROWS, !BIG>(g * RL + q, w)];
-            dft_pa<RL>(x);
+            dft_p<RL>(x);
             const int kb = kbase(g);
             float2 Tw = make_float2(1.f, 0.f);
             if constexpr (PTW) Tw = big_twiddle(d, f * (unsigned)kb);
@@ -928,8 +887,6 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
             }
         }
     }
-    if constexpr (PERSIST) lds_barrier();   // the next tile overwrites the LDS image: every last-stage read is done
-    }   // tiles of this workgroup
 }
 
 template <class T, class = void>
@@ -1050,7 +1007,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
         if ((rowsL % RG == 0) || g < rowsL) {
 #pragma unroll
             for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_pa<RL>(&xr[it * RL]);
+            dft_p<RL>(&xr[it * RL]);
         }
     }
     lds_barrier();   // every slot has been read
@@ -1099,7 +1056,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
             float2 x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_pa<RL>(x);
+            dft_p<RL>(x);
             const int kb = kbase(g);
             float2 Tw = big_twiddle(d2, f * (unsigned)kb);
             if (lane_ok) {
@@ -1240,7 +1197,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_pa
             float2 x[RL];
 #pragma unroll
             for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_pa<RL>(x);
+            dft_p<RL>(x);
 #pragma unroll
             for (int q = 0; q < RL; ++q)
                 u0[it * RL + q] = mid.first(x[dft_slot<RL>(q)], a0[it * RL + q], keep[it * RL + q]);
@@ -1281,7 +1238,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_pa
                 float2 x[RL];
 #pragma unroll
                 for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-                dft_pa<RL>(x);
+                dft_p<RL>(x);
                 const int kb = kbase(g);
                 float2 Tw = big_twiddle(d2, f * (unsigned)kb);
                 if (lane_ok) {
@@ -1427,7 +1384,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_de
         if ((rowsL % RG == 0) || g < rowsL) {
 #pragma unroll
             for (int q = 0; q < RL; ++q) xr[it * RL + q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_pa<RL>(&xr[it * RL]);
+            dft_p<RL>(&xr[it * RL]);
         }
     }
     lds_barrier();   // every slot has been read
@@ -1489,7 +1446,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_de
         float2 x[Q1];
 #pragma unroll
         for (int q = 0; q < Q1; ++q) x[q] = tile[lds_slot<true>(rg * Q1 + q, w)];
-        dft_pa<Q1>(x);
+        dft_p<Q1>(x);
         const float2 D = big_twiddle(d2, f * (unsigned)(L2 / Q1));
         float2 Tw = big_twiddle(d2, f * (unsigned)rg);
         if (w < wvalid) {
@@ -1583,7 +1540,6 @@ struct StoreRowWindow {
 }  // namespace fftk
 RCFM_NS_CLOSE
 }  // namespace rcfm
-#include "fft_dma.h"
 namespace rcfm {
 RCFM_NS_OPEN
 namespace fftk {
@@ -1678,93 +1634,10 @@ template <> struct is_plain_functor<StoreRowWindow> : std::true_type {};
 // Which pass kinds a functor pair is ever used with (prunes template instantiations).
 enum PassKinds : int { kAnyPass = 0, kStridedOnly = 1, kRowsOnly = 2 };
 
-// -DRCFM_FFT_PERSIST=1 builds the persistent form of the big / 400-point streaming passes as well (two resp. three
-// workgroups per CU walking their tiles; the environment variable RCFM_FFT_PERSIST=0 then switches back at run time).
-// Measured and NOT adopted (round 3, same-box alternation, no spills in either form): wideband FFT 2.44 vs 2.16 ms,
-// cfg4 7.46 vs 7.18 ms, cfg5 1.73 vs 1.61 ms -- workgroup dispatch between tiles is not what the passes wait for, and
-// a fixed tile list per workgroup loses the hardware's dynamic balancing.
-#ifndef RCFM_FFT_PERSIST
-#define RCFM_FFT_PERSIST 0
-#endif
-inline bool getenv_fft_persist() {
-    static const bool v = [] {
-        const char* e = std::getenv("RCFM_FFT_PERSIST");
-        return !(e && e[0] == '0');
-    }();
-    return v;
-}
-
-// RCFM_FFT_DMA (environment, read once): 1 = the streaming passes over big tiles load by LDS-DMA into two LDS buffers
-// (k_fft_tile_dma, one persistent workgroup per CU), 0 = k_fft_tile (two workgroups per CU, loads through VGPRs).
-#ifndef RCFM_FFT_DMA_DEFAULT
-#define RCFM_FFT_DMA_DEFAULT 0
-#endif
-inline bool getenv_fft_dma() {
-    static const bool v = [] {
-        const char* e = std::getenv("RCFM_FFT_DMA");
-        return e ? e[0] != '0' : RCFM_FFT_DMA_DEFAULT != 0;
-    }();
-    return v;
-}
-template <class T> struct plain_load_swap;
-template <bool S> struct plain_load_swap<LoadPlainT<S>> { static constexpr bool value = S; };
-template <class T> struct is_plain_store : std::false_type {};
-template <bool S> struct is_plain_store<StorePlainT<S>> : std::true_type {};
-
-// The DMA form applies when every 16-byte piece it fetches is aligned and inside the input: strided passes with whole
-// tiles (n_inner a multiple of 16) and even strides, rows passes whose lines are a multiple of 8 points at an even pitch.
-template <int LEN, bool ROWS>
-inline bool fft_dma_applies(const FftPassDev& d, dim3 grid, const float2* in) {
-    if (!getenv_fft_dma() || (reinterpret_cast<uintptr_t>(in) & 15u)) return false;
-    const FftPass& p = d.p;
-    const unsigned total = grid.x * grid.y * grid.z;
-    if (total < 2u * (unsigned)FftEngine::compute_units()) return false;   // nothing to pipeline
-    if ((d.in_batch | p.in_o1 | p.in_o2) & 1) return false;
-    if (ROWS) return LEN % 8 == 0 && (p.in_i & 1) == 0;
-    return p.n_inner % W == 0 && (p.in_l & 1) == 0 && p.in_i == 1;
-}
-
 template <int LEN, int A, int B, int C, int D, bool ROWS, class LoadOp, class StoreOp>
 inline void launch_fft_tile_one(const FftPassDev& d, dim3 grid, const LoadOp& ld, const StoreOp& st, hipStream_t s) {
     constexpr int T = tile_threads(LEN);
-    constexpr bool kResidentTile = big_tile_pair(LEN) || triple_tile(LEN);
-    if constexpr (W == 16 && big_tile_pair(LEN) && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value &&
-                  (!ROWS || LEN % 8 == 0)) {
-        if (fft_dma_applies<LEN, ROWS>(d, grid, ld.in)) {
-            const unsigned cus = (unsigned)FftEngine::compute_units() & ~7u;
-            hipLaunchKernelGGL((k_fft_tile_dma<LEN, A, B, C, D, ROWS, plain_load_swap<LoadOp>::value, StoreOp,
-                                               is_plain_store<StoreOp>::value>),
-                               dim3(cus), dim3(1024), 0, s, d, ld.in, st, grid);
-#ifdef RCFM_DMA_TRACE
-            {
-                static int shots = 0;
-                if (shots++ < 6) {
-                    long long t[32 * 8];
-                    (void)hipStreamSynchronize(s);
-                    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_dma_trace), sizeof(t));
-                    std::printf("k_fft_tile_dma<%d,%s> ticks per phase of workgroup 0 (wait+barrier, issue, stage 1, stage 2, stage 3, last stage; then the gap to the next tile)\n", LEN, ROWS ? "rows" : "strided");
-                    for (int i = 0; i < 24; ++i) {
-                        std::printf("  tile %2d:", i);
-                        for (int k = 0; k < 6; ++k) std::printf(" %6lld", t[i * 8 + k + 1] - t[i * 8 + k]);
-                        std::printf("   total %6lld\n", t[i * 8 + 6] - t[i * 8]);
-                    }
-                }
-            }
-#endif
-            return;
-        }
-    }
-    if constexpr (RCFM_FFT_PERSIST && kResidentTile && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
-        // streaming passes of long transforms: as many workgroups as the chip holds at once, each walking its tiles
-        const unsigned resident = (unsigned)((big_tile_pair(LEN) ? 2 : 3) * FftEngine::compute_units());
-        const unsigned total = grid.x * grid.y * grid.z;
-        if (getenv_fft_persist() && resident % 8 == 0 && total > resident) {
-            hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, ROWS, T, LoadOp, StoreOp, true>), dim3(resident), dim3(T), 0, s,
-                               d, ld, st, grid);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, ROWS, T, LoadOp, StoreOp, false>), grid, dim3(T), 0, s, d, ld, st, grid);
+    hipLaunchKernelGGL((k_fft_tile<LEN, A, B, C, D, ROWS, T, LoadOp, StoreOp>), grid, dim3(T), 0, s, d, ld, st);
 }
 
 template <int KIND = kAnyPass, class LoadOp, class StoreOp>
@@ -1775,7 +1648,7 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
                "FFT functor used with the wrong pass kind");
     const bool shape_ok = (rows || d.p.in_i == 1) && d.p.out_i == 1 && ((d.p.has_twiddle != 0) == !rows) &&
                           d.p.n_o1 * d.p.n_o2 <= 65535 && batch <= 65535;
-    if (shape_ok && !getenv_generic_fft()) {
+    if (shape_ok) {
         const dim3 grid((unsigned)((d.p.n_inner + W - 1) / W), (unsigned)(d.p.n_o1 * d.p.n_o2), (unsigned)batch);
         switch (d.p.L) {
 #define RCFM_CASE(LEN, A, B, C, D)                                                                            \
@@ -1820,7 +1693,7 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
         break;
         default: break;
     }
-    return fast && !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L &&
+    return fast && d1.p.load_along_l && !d2.p.load_along_l && d1.p.L == d2.p.L &&
            d1.p.n_inner == d2.p.n_inner && d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 &&
            d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
 }
@@ -1843,7 +1716,7 @@ inline bool fft_tile2_decim_applies(const FftPassDev& d1, const FftPassDev& d2, 
 #define RCFM_CASE(LEN, A, B, C, D, LEN2, E, F) fast = fast || (d1.p.L == LEN && d2.p.L == LEN2);
     RCFM_FFT_DECIM_PAIRS(RCFM_CASE)
 #undef RCFM_CASE
-    return fast && !getenv_generic_fft() && d1.p.load_along_l && !d2.p.load_along_l &&
+    return fast && d1.p.load_along_l && !d2.p.load_along_l &&
            d1.p.n_inner == d2.p.n_inner && d1.p.n_o1 * d1.p.n_o2 == 1 && d2.p.n_o1 * d2.p.n_o2 == 1 &&
            d1.p.out_k == d2.p.in_l && d2.p.in_i == 1 && d2.p.out_i == 1 && d2.p.has_twiddle && batch <= 65535;
 }

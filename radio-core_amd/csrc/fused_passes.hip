@@ -475,7 +475,7 @@ void middle_passes(const FftEngine& e, int from, int to, float2* tmp, int count,
 struct StorePhase {
     float* theta;
     __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
-        (theta + base)[off] = (RCFM_ABLATE & 8) ? v.x : atan2_over_pi(v.x, v.y);
+        (theta + base)[off] = atan2_over_pi(v.x, v.y);
     }
 };
 

@@ -9,12 +9,6 @@
 #include "kernels.h"
 
 #include <cmath>
-// RCFM_ABLATE & 16 (timing experiments only, wrong results; fft_kernel.h lists the bits): no taps in the pilot FIR
-#ifdef RCFM_ABLATE
-#define RCFM_ABLATE_K RCFM_ABLATE
-#else
-#define RCFM_ABLATE_K 0
-#endif
 #include "device_math.h"
 
 namespace rcfm {
@@ -429,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
 #pragma unroll
         for (int i = 0; i < PER / 2; ++i) acc[2 * i + 1].x = taps.pair[0].x * we[i].y;   // t = 0 of odd r
 #pragma unroll
-        for (int j = 0; j <= ((RCFM_ABLATE_K & 16) ? 0 : H); ++j) {
+        for (int j = 0; j <= H; ++j) {
             const v2f tp = taps.pair[j];
 #pragma unroll
             for (int i = 0; i < PER / 2; ++i) pk_fma_s(acc[2 * i], tp, we[i]);          // pairs j + i

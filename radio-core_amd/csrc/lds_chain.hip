@@ -32,7 +32,7 @@ namespace rcfm {
 namespace {
 
 using fftk::cmul;
-using fftk::dft_pa;
+using fftk::dft_p;
 using fftk::dft_slot;
 using fftk::lds_barrier;
 using fftk::twiddle_powers;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void chain_stage(float2* x, const float2* __restrict_
         const float2 w1 = tw[kp * step];          // W_MT^kp, issued ahead of the LDS reads
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = x[base + q * m];
-        dft_pa<R>(v);
+        dft_p<R>(v);
         float2 pw[R];
         twiddle_powers<R>(w1, pw);
 #pragma unroll
@@ -91,7 +91,7 @@ __device__ __forceinline__ int chain_last(const float2* x, int tid, float2* v) {
     const int g = tid < rows ? tid : 0;
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = x[g * R + q];
-    dft_pa<R>(v);
+    dft_p<R>(v);
     const int q1 = g / R1, q2 = g - q1 * R1;
     return q1 + R0 * q2;
 }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
                     const float sel = (k == p.a.merge) ? 1.f : 0.f;
                     u[q] = make_float2(fmaf(sel, m2.y, v[q].y * w), fmaf(sel, m2.x, v[q].x * w));   // swapped
                 }
-                dft_pa<R0>(u);
+                dft_p<R0>(u);
                 float2 pw[R0];
                 twiddle_powers<R0>(w1, pw);
 #pragma unroll

@@ -20,6 +20,8 @@ LIB_PATH = os.environ.get("RCFM_LIB") or os.path.join(os.path.dirname(_HERE), "_
 
 RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
 RCFM_OPT_LDS_CHAIN, RCFM_OPT_FUSED_TILES, RCFM_OPT_PHASE_LINK, RCFM_OPT_NARROW_TILES, RCFM_OPT_STATE_FENCE = 1, 2, 3, 4, 5   # rcfm_demod_set_option
+RCFM_OPT_PILOT_CHAIN, RCFM_OPT_DECIM_TILE, RCFM_OPT_LDS_DEEMPH = 6, 7, 8
+RCFM_TUNER_OPT_NARROW_TILES = 1                                                                                                # rcfm_tuner_set_option
 
 _ERR_SIZE, _ERR_INDEX, _ERR_RUNTIME, _ERR_ARG, _ERR_STATE = -1, -2, -3, -4, -5
 
@@ -42,6 +44,10 @@ SIGNATURES = {
     "rcfm_stream_sync": [_vp],
     "rcfm_stream_create": [ctypes.POINTER(_vp)],
     "rcfm_stream_destroy": [_vp],
+    "rcfm_arena_create": [_sz, ctypes.POINTER(_vp)],
+    "rcfm_arena_bind": [_vp],
+    "rcfm_arena_stats": [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)],
+    "rcfm_arena_destroy": [_vp],
     "rcfm_tuner_create": [_i64, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp)],
     "rcfm_tuner_load": [_vp, _vp, _vp],
     "rcfm_tuner_shard": [_vp, _i, _i],
@@ -50,7 +56,10 @@ SIGNATURES = {
     "rcfm_tuner_spectrum_layout": [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "rcfm_tuner_attach_spectrum": [_vp, _vp, _i, _i],
     "rcfm_tuner_window": [_vp, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "rcfm_tuner_window_layout": [_vp, _i, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "rcfm_tuner_attach_window": [_vp, _vp, _i, _i],
     "rcfm_tuner_adopt": [_vp, _i, _i, _vp],
+    "rcfm_tuner_set_option": [_vp, _i, _i],
     "rcfm_tuner_destroy": [_vp],
     "rcfm_demod_create": [_i, _i, _i, _i, _dbl, _i, ctypes.POINTER(_vp)],
     "rcfm_demod_run": [_vp, _i, _i, _vp, _vp, _vp],
@@ -88,6 +97,7 @@ SIGNATURES = {
     "rcfm_discriminator": [_i, _i, _vp, _vp, _vp],
     "rcfm_fft_describe": [_i64, _i, _vp],
     "rcfm_fft_c2c": [_i64, _i, _i, _vp, _vp, _vp],
+    "rcfm_fft_c2c_plan": [_i64, ctypes.POINTER(_i64), _i, _i, _i, _vp, _vp, _vp],
     "rcfm_fft_c2c_rocfft": [_i64, _i, _i, _vp, _vp, _vp],
     "rcfm_profile_stage_count": [],
     "rcfm_profile_enable": [ctypes.c_uint64],
@@ -236,3 +246,68 @@ class Handle:
         self.value = None
         if status != 0 and not sys.is_finalizing():
             warnings.warn("librcfm destroy returned status %d" % status, ResourceWarning)
+
+
+# ---- placement (rcfm_arena_*) ----------------------------------------------------------------------------------------
+
+_arena_stack = []
+
+
+def current_arena():
+    """The Arena whose `with` block is open on this thread of control (None: hipMalloc per workspace)."""
+    return _arena_stack[-1] if _arena_stack else None
+
+
+class Arena:
+    """ONE placement draw for every large workspace of the handles built inside it (include/rcfm.h, rcfm_arena_*;
+    profiles/r04_k_placement.md: where hipMalloc puts a multi-GB workspace moves a cfg4 buffer by 1.5 - 4 %).
+
+        with radiocore.tools.Arena(20 << 30) as arena:      # one 20 GiB device block (0: 1 GiB blocks on demand)
+            tuner = Tuner(cuda=True); ... add_channel(..., WBFM(..., cuda=True)) ...
+        # the objects remember the arena: their device handles are created lazily (first load / run) inside it
+
+    The arena must outlive those objects (close() refuses while their handles are alive).  No reference counterpart."""
+
+    def __init__(self, block_bytes=0):
+        h = _vp()
+        check(lib().rcfm_arena_create(_sz(int(block_bytes)), ctypes.byref(h)))
+        self._handle = Handle(h, lib().rcfm_arena_destroy)
+
+    @property
+    def value(self):
+        return self._handle.value
+
+    def __enter__(self):
+        _arena_stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _arena_stack.pop()
+        return False
+
+    def stats(self):
+        r, u, n = _sz(), _sz(), _sz()
+        check(lib().rcfm_arena_stats(self._handle.value, ctypes.byref(r), ctypes.byref(u), ctypes.byref(n)))
+        return {"reserved_bytes": int(r.value), "used_bytes": int(u.value), "live_pieces": int(n.value)}
+
+    def close(self):
+        if self._handle.value:
+            check(lib().rcfm_arena_destroy(self._handle.value))
+            self._handle.value = None
+
+
+class bound:
+    """`with bound(arena):` -- handles created by librcfm inside the block belong to `arena` (None: no-op)."""
+
+    def __init__(self, arena):
+        self._arena = arena
+
+    def __enter__(self):
+        if self._arena is not None:
+            check(lib().rcfm_arena_bind(self._arena.value))
+        return self
+
+    def __exit__(self, *exc):
+        if self._arena is not None:
+            check(lib().rcfm_arena_bind(None))
+        return False

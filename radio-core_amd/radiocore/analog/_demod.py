@@ -39,14 +39,16 @@ class Demodulator(Injector):
         # ... but the librcfm handle (plans, tables, workspaces: ~12 MB for a 240 kHz WBFM channel) is created on first
         # use: a Tuner with thousands of channels that only ever calls run_all() never needs the per-channel handles
         self._h = None
+        self._arena = hip.current_arena()      # `with radiocore.tools.Arena(...)`: the handle is built inside it
         self._binding = None       # (weakref to the batched hip.Handle, channel index): Tuner._bind_states
 
     @property
     def _handle(self):
         if self._h is None:
             h = ctypes.c_void_p()
-            hip.check(self._lib.rcfm_demod_create(self._KIND, self._batch, self._input_size, self._output_size,
-                                                  self._tau, self._chunk, ctypes.byref(h)))
+            with hip.bound(self._arena):
+                hip.check(self._lib.rcfm_demod_create(self._KIND, self._batch, self._input_size, self._output_size,
+                                                      self._tau, self._chunk, ctypes.byref(h)))
             self._h = hip.Handle(h, self._lib.rcfm_demod_destroy)
             self._apply_binding(move_history=0)      # new handle: the batched caller has carried the state so far
         return self._h

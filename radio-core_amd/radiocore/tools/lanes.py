@@ -33,16 +33,18 @@ class Lanes:
     (``demodulator.reset()``), ``drain()`` first.
     """
 
-    def __init__(self, tuner: Tuner, depth: int = 2):
+    def __init__(self, tuner: Tuner, depth: int = 2, timing: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self._torch = hip.torch()
+        self._timing = bool(timing)     # events that can be timed: overlap_ms() (tests, tuning), not needed otherwise
         self._base = tuner
         tuner._arm_state_fence()
         self._tuners = [tuner] + [tuner._lane_clone() for _ in range(depth - 1)]
         self._streams = [self._torch.cuda.Stream() for _ in range(depth)]
         self._next = 0
-        self._pending = {}          # ticket -> (event, audio tensor)
+        self._pending = {}          # ticket -> (end event, audio tensor, event behind the load = last reader of the input)
+        self._spans = {}            # timing=True: ticket -> (start event, end event)
 
     @property
     def depth(self) -> int:
@@ -60,16 +62,37 @@ class Lanes:
             t._sync_lane(self._base)            # channels added since the lane was made
         st = self._streams[k]
         st.wait_stream(self._torch.cuda.current_stream())     # whatever produced the buffer
+        if isinstance(input_signal, self._torch.Tensor) and input_signal.is_cuda:
+            # the caller's tensor is read on the lane's stream: the caching allocator must not hand its memory to
+            # current-stream work before the lane's FFT has consumed it
+            input_signal.record_stream(st)
         with self._torch.cuda.stream(st):
+            start = self._event(st) if self._timing else None
             t.load(input_signal)
+            loaded = self._event(st)            # the wideband FFT is the LAST reader of the input buffer
             audio = t._run_each_device() if each else t._run_all_device(chunk)
-            ev = st.record_event()
-        self._pending[ticket] = (ev, audio)
+            ev = self._event(st)
+        self._pending[ticket] = (ev, audio, loaded)
+        if self._timing:
+            self._spans[ticket] = (start, ev)
         return ticket
+
+    def _event(self, stream):
+        e = self._torch.cuda.Event(enable_timing=self._timing)
+        e.record(stream)
+        return e
+
+    def overlap_ms(self, earlier: int, later: int) -> float:
+        """timing=True only: how long before the END of buffer `earlier` the lane of buffer `later` started working
+        (positive: the two buffers overlapped on the device; negative: `later` started that long after `earlier` had
+        finished).  Both must have completed (result() / drain())."""
+        start, _ = self._spans[later]
+        _, end = self._spans[earlier]
+        return float(start.elapsed_time(end))
 
     def result(self, ticket: int, numpy_output: bool = True):
         """The audio of one submitted buffer, [C, A, ch] float32 (the shard's block after Tuner.shard)."""
-        ev, audio = self._pending.pop(ticket)
+        ev, audio, _ = self._pending.pop(ticket)
         device_output = self._base._cuda and not numpy_output
         if device_output:
             cur = self._torch.cuda.current_stream()
@@ -83,12 +106,15 @@ class Lanes:
         return audio if device_output else hip.to_host(audio)
 
     def hold_current_stream(self, ticket: int):
-        """Order the CURRENT stream behind one submitted buffer: for a caller that recycles the buffer's storage
-        stream-ordered (``with feeder.next() as x: t = lanes.submit(x); lanes.hold_current_stream(t)`` -- the Feeder
-        frees the slot behind the current stream, which must therefore wait for the lane that still reads it)."""
-        self._torch.cuda.current_stream().wait_event(self._pending[ticket][0])
+        """Order the CURRENT stream behind the last READ of one submitted buffer's input (the wideband FFT of
+        Tuner.load; the channel stages read the spectrum, not the input): for a caller that recycles the buffer's
+        storage stream-ordered (``with feeder.next() as x: t = lanes.submit(x); lanes.hold_current_stream(t)`` -- the
+        Feeder frees the slot behind the current stream, which must therefore wait for the lane that still reads it).
+        It does NOT wait for the buffer's audio: the next submit() waits for the current stream, and a wait for the
+        whole buffer there would run the lanes one after the other."""
+        self._torch.cuda.current_stream().wait_event(self._pending[ticket][2])
 
     def drain(self):
         """Wait for everything submitted so far (results stay collectable)."""
-        for ev, _ in self._pending.values():
+        for ev, _, _ in self._pending.values():
             ev.synchronize()

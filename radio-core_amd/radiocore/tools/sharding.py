@@ -127,8 +127,15 @@ class SpectrumRing:
         acquire(i)      the tuner now holds buffer i's spectrum for this rank's channels: run_all() may follow.
     Callers prime the ring with submit(0 .. lookahead - 1) and then alternate submit(i + lookahead) / acquire(i).
 
+    Storage: a rank needs a WHOLE spectrum only for the buffers it owns -- ceil((lookahead + 1) / G) of the lookahead + 1
+    in flight, two at the default lookahead = G; every other buffer in flight needs room for this rank's window only
+    (Tuner.window_slot: [halo | nbins | halo]).  At cfg4 / G = 8 that is 2 x 1.92 GB + 9 x 0.26 GB per rank instead of
+    9 x 1.92 GB.  A rank whose window wraps around the ends of the spectrum (its halos repeat the other end) keeps
+    whole slots for everything.
+
     `tuner` needs: window(n, first, count), spectrum_slot(n), attach(slot, n, loaded), load(x, whole=True),
-    adopt(n, first, count) and shard(first, count) -- radiocore.tools.Tuner, or a stand-in (tests).
+    adopt(n, first, count) and shard(first, count) -- radiocore.tools.Tuner, or a stand-in (tests); optionally
+    window_slot(n, first, count) (None: no window storage for that range) and attach_window(slot, n).
     The reference has nothing of the kind: its one process does everything (examples/multi_fm_server.py:95-106).
     """
 
@@ -147,8 +154,20 @@ class SpectrumRing:
         tuner.shard(lo, hi - lo)
         self.segments = [window_segments(*tuner.window(self.n, a, b - a), self.n) if b > a else []
                          for a, b in self.ranges]
-        self.slots = [tuner.spectrum_slot(self.n) for _ in range(self.lookahead + 1)]
-        self.halo = int(getattr(self.slots[0], "rcfm_halo", (self.slots[0].shape[0] - self.n) // 2))
+        # whole slots for owned buffers, window-sized ones for the rest (when this rank's window allows it)
+        in_flight = self.lookahead + 1
+        probe = None
+        if self.world > 1 and hi > lo and hasattr(tuner, "window_slot") and len(self.segments[self.rank]) == 1:
+            probe = tuner.window_slot(self.n, lo, hi - lo)
+        if probe is not None:
+            self._full = [tuner.spectrum_slot(self.n) for _ in range(-(-in_flight // self.world))]
+            self._win = [probe] + [tuner.window_slot(self.n, lo, hi - lo) for _ in range(in_flight - 1)]
+        else:
+            self._full = [tuner.spectrum_slot(self.n) for _ in range(in_flight)]
+            self._win = []
+        self.slots = self._full + self._win
+        self.full_slots, self.window_slots = len(self._full), len(self._win)
+        self.halo = int(getattr(self._full[0], "rcfm_halo", (self._full[0].shape[0] - self.n) // 2))
         self._pending = {}      # buffer index -> (own, outstanding works, event of the owner's FFT)
         self._next_submit = 0
         self._next_acquire = 0
@@ -165,8 +184,25 @@ class SpectrumRing:
     def owner(self, i):
         return i % self.world
 
+    def _slot_of(self, i):
+        """Storage of buffer i on this rank: the k-th owned buffer takes whole slot k mod F; with window slots the j-th
+        buffer of another owner takes window slot j mod (lookahead + 1).  Any lookahead + 1 consecutive buffers hold at
+        most F owned ones, so no two buffers in flight share storage."""
+        if not self._win:
+            return self._full[i % len(self._full)]
+        if self.owner(i) == self.rank:
+            return self._full[(i // self.world) % len(self._full)]
+        owned_before = max(0, (i - self.rank + self.world - 1) // self.world)
+        return self._win[(i - owned_before) % len(self._win)]
+
+    def slot_bytes(self):
+        return sum(int(t.numel()) * t.element_size() for t in self.slots)
+
     def _views(self, slot, rank):
         # (a rank without channels -- C < G -- reads nothing: no pieces, no transfer)
+        if getattr(slot, "rcfm_window", None) is not None:      # a window slot holds this rank's one segment from `halo` on
+            (a, b), = self.segments[rank]
+            return [slot[self.halo:self.halo + (b - a)]]
         return [slot[self.halo + a:self.halo + b] for a, b in self.segments[rank] if b > a]
 
     def bytes_sent_per_buffer(self):
@@ -180,7 +216,7 @@ class SpectrumRing:
             raise RuntimeError("SpectrumRing.submit: every slot is in flight; acquire buffer %d first" % self._next_acquire)
         self._next_submit += 1
         dist = self._dist
-        slot = self.slots[i % len(self.slots)]
+        slot = self._slot_of(i)
         own = self.owner(i) == self.rank
         works = []
         event = None
@@ -263,10 +299,13 @@ class SpectrumRing:
             w.wait()                  # RCCL: orders the current stream behind the transfer
         if self._timing is not None:
             self._timing["wait"].append((ea, self._mark(None)) if ea is not None else 1e3 * (time.perf_counter() - t0))
-        slot = self.slots[i % len(self.slots)]
+        slot = self._slot_of(i)
         lo, hi = self.ranges[self.rank]
         if own:
             self.tuner.attach(slot, self.n, (0, self.channels))
+        elif getattr(slot, "rcfm_window", None) is not None:
+            self.tuner.attach_window(slot, self.n)
+            self.tuner.adopt(self.n, lo, hi - lo)
         else:
             self.tuner.attach(slot, self.n, None)
             self.tuner.adopt(self.n, lo, hi - lo)
@@ -275,8 +314,13 @@ class SpectrumRing:
 
     def enable_timing(self):
         """From now on: time of every owned buffer's FFT and sends (on the owner's stream) and how long the channel
-        stream had to wait for a buffer's bins in acquire().  timing_summary() returns the means in milliseconds."""
+        stream had to wait for a buffer's bins in acquire().  timing_summary() returns the means in milliseconds.
+        The owner's stream then waits for its sends before it takes the next buffer -- NOT the shipping schedule: time
+        throughput with timing off (bench.py runs a pass of its own for these numbers, after the timed region)."""
         self._timing = {"fft": [], "send": [], "wait": []}
+
+    def disable_timing(self):
+        self._timing = None
 
     def _mark(self, stream):
         if self._timing is None or self._side is None:
@@ -301,3 +345,10 @@ class SpectrumRing:
         """Complete every transfer that has been posted (acquire whatever is still in flight, without running it)."""
         while self._next_acquire < self._next_submit:
             self.acquire(self._next_acquire)
+
+    def close(self):
+        """After drain(): hand the tuner its own spectrum storage back and let the slots go."""
+        if hasattr(self.tuner, "detach"):
+            self.tuner.detach(self.n)
+        self.slots = self._full = self._win = []
+        self._staging = None

@@ -45,6 +45,7 @@ class Tuner(Injector):
     def __init__(self, cuda: bool = False):
         self._cuda = cuda
         super().__init__(self._cuda)
+        self._arena = hip.current_arena()     # `with radiocore.tools.Arena(...)`: the device handles are built inside it
         self._input_frequency = 0.0
         self._input_bandwidth = 0.0
         self._bounds: List[Channel] = []
@@ -143,7 +144,8 @@ class Tuner(Injector):
                                     (ctypes.c_int32 * len(bws))(*bws))
             _, roll_a, bw_a = self._abi_arrays
             h = ctypes.c_void_p()
-            hip.check(self._lib.rcfm_tuner_create(n, len(self._bounds), roll_a, bw_a, ctypes.byref(h)))
+            with hip.bound(self._arena):
+                hip.check(self._lib.rcfm_tuner_create(n, len(self._bounds), roll_a, bw_a, ctypes.byref(h)))
             self._handle = hip.Handle(h, self._lib.rcfm_tuner_destroy)
             self._handle_key = key
             self._loaded_size = None
@@ -206,6 +208,33 @@ class Tuner(Injector):
         hip.check(self._lib.rcfm_tuner_attach_spectrum(self._same_handle(n, "attach"), hip.ptr(slot), int(first), int(count)))
         self._slot = slot          # keeps the storage alive while the handle points at it
         self._loaded_size = int(n) if loaded is not None else None
+
+    def detach(self, n):
+        """Back to the handle's own spectrum storage (nothing loaded)."""
+        hip.check(self._lib.rcfm_tuner_attach_spectrum(self._same_handle(n, "detach"), None, 0, 0))
+        self._slot = None
+        self._loaded_size = None
+
+    def window_slot(self, n, first, count):
+        """Device storage for just the bins channels [first, first + count) read -- complex64 [halo + nbins + halo], the
+        window's first bin at element `halo` -- or None when that window wraps around the ends of the spectrum (such a
+        range needs a whole spectrum_slot).  What a rank that never owns a buffer keeps per buffer in flight."""
+        halo, nb = ctypes.c_int64(), ctypes.c_int64()
+        rc = self._lib.rcfm_tuner_window_layout(self._device_tuner(int(n)), int(first), int(count), ctypes.byref(halo),
+                                                ctypes.byref(nb))
+        if rc != 0:
+            return None
+        t = hip.empty((int(nb.value) + 2 * int(halo.value),), self._torch.complex64)
+        t.rcfm_halo = int(halo.value)
+        t.rcfm_window = (int(first), int(count))
+        return t
+
+    def attach_window(self, slot, n):
+        """Use `slot` (from window_slot) as the spectrum of its channel range; adopt() must follow once the bins are in."""
+        first, count = slot.rcfm_window
+        hip.check(self._lib.rcfm_tuner_attach_window(self._same_handle(n, "attach_window"), hip.ptr(slot), first, count))
+        self._slot = slot
+        self._loaded_size = None
 
     def window(self, n, first, count):
         """(first_bin, nbins): the bins of an n-point spectrum that channels [first, first + count) read, modulo n."""
@@ -363,12 +392,13 @@ class Tuner(Injector):
         key = (kind, len(self._bounds), B, A, tau, int(chunk)) + ((opts,) if opts != (True, True, True, 1) else ())
         if key not in self._batched:
             h = ctypes.c_void_p()
-            hip.check(self._lib.rcfm_demod_create(kind, len(self._bounds), B, A, tau, int(chunk), ctypes.byref(h)))
+            with hip.bound(self._arena):
+                hip.check(self._lib.rcfm_demod_create(kind, len(self._bounds), B, A, tau, int(chunk), ctypes.byref(h)))
             self._batched[key] = hip.Handle(h, self._lib.rcfm_demod_destroy)
             for opt, on in zip((hip.RCFM_OPT_LDS_CHAIN, hip.RCFM_OPT_FUSED_TILES, hip.RCFM_OPT_PHASE_LINK), opts[:3]):
                 if not on:
                     hip.check(self._lib.rcfm_demod_set_option(h, opt, 0))
-            if opts[3] != 1:
+            if opts[3] != 1:   # (rcfm_pipeline_run hands the same setting to the tuner's inverse FFT of each chunk)
                 hip.check(self._lib.rcfm_demod_set_option(h, hip.RCFM_OPT_NARROW_TILES, opts[3]))
             self._bind_states(key, self._batched[key])
             if self._state_fence and kind != hip.RCFM_FM:    # after the binding: the fence travels with the state buffer
@@ -420,6 +450,7 @@ class Tuner(Injector):
         """A second Tuner over the SAME channel list, demodulator objects and de-emphasis state, with its own device
         handles (spectrum, workspaces): what one more stream needs to work on the next buffer."""
         t = Tuner(cuda=self._cuda)
+        t._arena = self._arena
         t._is_lane = True
         t._sync_lane(self)
         return t

@@ -43,12 +43,18 @@ def test_two_rank_dry_run_prints_one_contract_line(parallelism):
     assert abs(r["value"] - r["config"]["wideband_samples"] / (r["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * r["value"]
     assert r["roofline"]["traffic"] is None                          # the committed PMC passes describe one GPU
     assert r["cpu_baseline"] is None                                 # rank 0 at N = 1 only
+    assert r["rccl_ranks"] == 0                                      # a gloo dry run: no RCCL communicator
+    assert "rotating" not in r                                       # one partitioning was asked for
+    assert r["stages"]["tuner_fft_N"]["ms"] > 0 and r["roofline"]["stage"] in r["stages"]
     assert r["channel_stage_value"]["value"] > 0
     assert r["pcie_inclusive"]["value"] > 0                          # the N > 1 line always carries the host-fed rate
     if parallelism == "rotating":
         assert r["amdahl_bound_speedup"] == 2.0 and "rotating FFT owner" in r["config"]["parallelism"]
         ro = r["rotating_owner"]
-        assert ro["lookahead"] == 2 and ro["spectrum_slots"] == 3 and ro["ffts_per_rank_per_buffer"] == 0.5
+        assert ro["lookahead"] == 2 and ro["ffts_per_rank_per_buffer"] == 0.5
+        # three buffers in flight: whole slots for all of them, or two whole ones (the owned buffers) + three windows
+        assert (ro["full_slots"], ro["window_slots"]) in ((3, 0), (2, 3))
+        assert ro["spectrum_slots"] == ro["full_slots"] + ro["window_slots"] and ro["slot_bytes"] > 0
         assert 0 < ro["bytes_sent_per_owned_buffer"] <= 8 * r["config"]["wideband_samples"]
     else:
         assert 1.0 < r["amdahl_bound_speedup"] < 2.0
@@ -80,3 +86,46 @@ def test_a_stalled_rank_fails_loudly_instead_of_hanging():
     assert err, out.stderr[-2000:]
     msg = json.loads(err[-1])
     assert msg["rank"] == 0 and msg["world"] == 2 and "no progress" in msg["error"] and msg["phase"]
+
+
+@pytest.mark.timeout(900)
+def test_plain_python_launch_starts_its_own_ranks_and_reports_both_partitionings():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver starts N = 1): bench.py re-executes itself
+    under torch.distributed.run with two ranks, rank 0 prints ONE line with n_gpus == 2, the replicated partitioning as
+    `value` and the rotating owner in the `rotating` block of the same launch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RCFM_BENCH_DEVICE="0", RCFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "small"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and len(r["per_rank"]) == 2
+    assert "wideband FFT replicated" in r["config"]["parallelism"] and 1.0 < r["amdahl_bound_speedup"] < 2.0
+    rot = r["rotating"]
+    assert "error" not in rot, rot
+    assert rot["value"] > 0 and rot["ms_per_step"] > 0 and len(rot["per_rank"]) == 2
+    assert "rotating FFT owner" in rot["parallelism"] and rot["amdahl_bound_speedup"] == 2.0
+    assert rot["gather_check"]["finite"] and rot["gather_check"]["blocks_with_audio"] == 2
+    assert rot["rotating_owner"]["lookahead"] == 2 and rot["vs_replicated"] > 0
+    for row in rot["per_rank"]:
+        assert row["owned_buffers"] >= 1
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rotating_leg_still_publishes_the_replicated_line():
+    """The second leg of a 'both' launch dies (RCFM_BENCH_FAIL_ROTATING=1 raises on rank 1 at its start; rank 0 then
+    waits for a peer that never comes and its watchdog fires): the run ends within the leg's own time limit with the
+    replicated line on stdout and the diagnosis in its `rotating` block."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RCFM_BENCH_DEVICE="0", RCFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RCFM_BENCH_FAIL_ROTATING="1", RCFM_BENCH_TIMEOUT_ROTATING="10")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "small",
+           "--no-pcie"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0
+    assert "error" in r["rotating"] and r["rotating"]["rank"] == 0 and r["rotating"]["phase"]

@@ -110,32 +110,37 @@ def test_engine_vs_rocfft_four_passes_at_a_billion_points():
     assert err <= 2e-5 * peak, (err, peak)
 
 
-@pytest.mark.parametrize("n,plan", [(384000, "640,600"), (375000, "600,625"), (400000, "625,640")])
-def test_big_tiles_in_both_roles(n, plan, monkeypatch):
+def _run_plan(n, plan, batch, inverse, x):
+    import ctypes
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    xd = hip.to_device(x, torch.complex64)
+    yd = hip.empty(xd.shape, torch.complex64)
+    lens = (ctypes.c_int64 * len(plan))(*plan)
+    hip.check(lib.rcfm_fft_c2c_plan(n, lens, len(plan), batch, int(inverse), hip.ptr(xd), hip.ptr(yd), hip.stream()))
+    torch.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,plan", [(384000, (640, 600)), (375000, (600, 625)), (400000, (625, 640))])
+def test_big_tiles_in_both_roles(n, plan):
     """The 600 / 625 / 640-point tiles (two 1024-thread workgroups per CU, twiddles as powers of one global table
     entry, XOR-swizzled rows image) in the roles the hot-path plans do not use them in: the planner's wideband plans
-    run 600 and 625 strided and 640 as rows; forced two-pass plans here run 640 and 625 strided and 600, 625, 640 as
-    rows.  (RCFM_FFT_FORCE is read when the engine of a length is first built.)"""
-    monkeypatch.setenv("RCFM_FFT_FORCE", plan)
+    run 600 and 625 strided and 640 as rows; two-pass plans given through rcfm_fft_c2c_plan run 640 and 625 strided and
+    600, 625, 640 as rows."""
     r = np.random.default_rng(n)
     x = (r.standard_normal((2, n)) + 1j * r.standard_normal((2, n))).astype(np.complex64)
     want = np.fft.fft(x.astype(np.complex128), axis=1).astype(np.complex64)
-    assert rel_err(_run(n, 2, False, x), want) <= 2e-6
-    assert rel_err(_run(n, 2, True, want), x * n) <= 4e-6
+    assert rel_err(_run_plan(n, plan, 2, False, x), want) <= 2e-6
+    assert rel_err(_run_plan(n, plan, 2, True, want), x * n) <= 4e-6
 
 
-@pytest.mark.timeout(600)
-def test_lds_dma_streaming_passes_in_a_subprocess():
-    """The LDS-DMA form of the big-tile streaming passes (csrc/fft_dma.h: one persistent workgroup per CU, tile i+1
-    fetched by global_load_lds into the second LDS buffer while tile i is transformed, counted vmcnt waits) is not the
-    default -- it measured slower or equal, profiles/r04_a_lds_dma.md -- but it stays correct: RCFM_FFT_DMA is read once
-    per process, so tools/dma_check.py runs in its own (forced two-pass plans with 600 / 625 strided and 640 rows against
-    torch.fft, N = 1e8 and 2.4e8 against rocFFT)."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = dict(os.environ, RCFM_FFT_DMA="1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dma_check.py")], env=env, cwd=ROOT,
-                         capture_output=True, text=True, timeout=550)
-    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-2000:] + out.stderr[-2000:]
+def test_plan_entry_refuses_lengths_that_do_not_multiply_to_n():
+    import ctypes
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    x = hip.empty((240000,), torch.complex64)
+    lens = (ctypes.c_int64 * 2)(480, 480)
+    assert lib.rcfm_fft_c2c_plan(240000, lens, 2, 1, 0, hip.ptr(x), hip.ptr(x), hip.stream()) != 0

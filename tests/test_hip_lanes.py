@@ -140,3 +140,37 @@ def test_lanes_with_mixed_channel_sets():
         assert len(got) == len(want[i]) == 6
         for g, w in zip(got, want[i]):
             assert g.shape == w.shape and np.array_equal(g, w), i
+
+
+def test_feeder_recipe_keeps_the_lanes_overlapped():
+    """The documented host-fed recipe -- ``with feeder.next() as x: t = lanes.submit(x); lanes.hold_current_stream(t)`` --
+    must not serialise the lanes: the current stream (and with it the next submit) waits for the wideband FFT of the
+    buffer, the last reader of the feeder's slot, not for the buffer's audio.  Asserted on the device's own clock
+    (timing events): lane i + 1 starts working BEFORE lane i has finished, and the audio is still bit-identical."""
+    import radiocore as rc
+    from radiocore.tools import Feeder, Lanes
+
+    kind, C, B, A, n = "WBFM", 16, 240000, 48000, 4_800_000
+    ref_tuner, bufs = _band(rc, kind, C, B, A, n, seed=9)
+    want = []
+    for x in bufs:
+        ref_tuner.load(x)
+        want.append(ref_tuner.run_all())
+    tuner, _ = _band(rc, kind, C, B, A, n, seed=9)
+    lanes = Lanes(tuner, depth=2, timing=True)
+    feeder = Feeder(n, depth=2)
+    tickets = []
+    feeder.submit(bufs[0])
+    for i in range(len(bufs)):
+        if i + 1 < len(bufs):
+            feeder.submit(bufs[i + 1])
+        with feeder.next() as x:
+            tickets.append(lanes.submit(x))
+            lanes.hold_current_stream(tickets[-1])
+    got = [lanes.result(t) for t in tickets]
+    feeder.close()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), i
+    overlaps = [lanes.overlap_ms(tickets[i], tickets[i + 1]) for i in range(len(tickets) - 1)]
+    # every buffer but the first (whose copy nothing hides) starts while its predecessor is still running
+    assert sum(o > 0 for o in overlaps[1:]) >= len(overlaps) - 2, overlaps

@@ -38,6 +38,7 @@ class FakeTuner:
 
     def __init__(self):
         self.slot = None
+        self.base = 0                                # first bin the attached storage holds at element HALO
         self.loaded = None
         self.shard_range = None
         self.loads = 0
@@ -72,8 +73,25 @@ class FakeTuner:
         t.rcfm_halo = HALO
         return t
 
+    def window_slot(self, n, first, count):
+        """[halo | the window's bins | halo], or None when the window wraps or touches the ends (rcfm_tuner_window_layout)."""
+        fb, nb = self.window(n, first, count)
+        if count == 0 or nb >= n or fb < HALO or fb + nb > n - HALO:
+            return None
+        t = torch.full((nb + 2 * HALO,), complex(np.nan, np.nan), dtype=torch.complex64)
+        t.rcfm_halo = HALO
+        t.rcfm_window = (first, count)
+        t.first_bin = fb
+        return t
+
     def attach(self, slot, n, loaded=None):
-        self.slot, self.loaded = slot, loaded
+        self.slot, self.loaded, self.base = slot, loaded, 0
+
+    def attach_window(self, slot, n):
+        self.slot, self.loaded, self.base = slot, None, slot.first_bin
+
+    def detach(self, n):
+        self.slot, self.loaded, self.base = None, None, 0
 
     def load(self, x, whole=False):
         assert whole
@@ -86,13 +104,17 @@ class FakeTuner:
 
     def adopt(self, n, first, count):
         s = self.slot
+        if getattr(s, "rcfm_window", None) is not None:
+            assert s.rcfm_window == (first, count)
+            self.loaded = (first, count)
+            return
         s[:HALO] = s[N:N + HALO]                 # (the real adopt copies only the window's part: NaN stays NaN elsewhere)
         s[HALO + N:] = s[HALO:2 * HALO]
         self.loaded = (first, count)
 
     def read(self, c):
         assert self.loaded[0] <= c < self.loaded[0] + self.loaded[1]
-        idx = HALO + CENTRES[c] + torch.arange(-40, 41)          # through the halo, no modulo: like the gather kernel
+        idx = HALO + CENTRES[c] - self.base + torch.arange(-40, 41)   # through the halo, no modulo: like the gather kernel
         return self.slot[idx]
 
 
@@ -135,17 +157,31 @@ def _worker(rank, world, port, lookahead, buffers, out_dir, channels=C):
     ok = ok and t["fft_count"] == owned and t["send_count"] == owned and t["wait_count"] == buffers
     ok = ok and t["fft_ms"] >= 0 and t["send_ms"] >= 0 and t["wait_ms"] >= 0
     dist.barrier()
-    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(ok), ring.bytes_sent_per_buffer()]))
+    # storage: whole slots for the buffers this rank owns, window-sized ones for the others when its window allows it
+    in_flight = ring.lookahead + 1
+    if ring.window_slots:
+        ok = ok and ring.full_slots == -(-in_flight // world) and ring.window_slots == in_flight
+        nb = tuner.window(N, lo, hi - lo)[1]
+        ok = ok and ring.slot_bytes() == 8 * (ring.full_slots * (N + 2 * HALO) + in_flight * (nb + 2 * HALO))
+    else:
+        ok = ok and ring.full_slots == in_flight
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([int(ok), ring.bytes_sent_per_buffer(), ring.window_slots]))
+    ring.drain()
+    ring.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,lookahead", [(2, None), (2, 1), (3, None), (3, 5)])
 def test_rotating_owner_delivers_every_window(tmp_path, world, lookahead):
     mp.spawn(_worker, args=(world, _free_port(), lookahead, 9, str(tmp_path)), nprocs=world, join=True)
+    windowed = []
     for r in range(world):
-        ok, sent = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
+        ok, sent, win = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
         assert ok == 1, r
         assert 0 < sent < 8 * N * (world - 1)                      # windows, not whole spectra
+        windowed.append(int(win) > 0)
+    # rank 0's first channel wraps around bin 0: it keeps whole slots; the last rank's window lies inside the spectrum
+    assert windowed[0] is False and windowed[-1] is True
 
 
 def test_more_ranks_than_channels(tmp_path):
@@ -153,7 +189,7 @@ def test_more_ranks_than_channels(tmp_path):
     transfer and still walks the schedule (it owns every third buffer's FFT)."""
     mp.spawn(_worker, args=(3, _free_port(), None, 7, str(tmp_path), 2), nprocs=3, join=True)
     for r in range(3):
-        ok, sent = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
+        ok, sent, win = np.load(os.path.join(str(tmp_path), "ok%d.npy" % r))
         assert ok == 1, r
     sys.path.insert(0, os.path.join(ROOT, "radio-core_amd"))
     from radiocore.tools.sharding import channel_range

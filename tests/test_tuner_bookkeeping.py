@@ -16,6 +16,8 @@ import radiocore_oracle as oracle
 
 
 class _FakeTensor:
+    is_cuda = True
+
     def __init__(self, shape):
         self.shape = tuple(shape)
 
@@ -164,6 +166,13 @@ def test_launch_plan_groups_and_shard(fake_backend):
 
 
 class _FakeEvent:
+    def __init__(self, enable_timing=False):
+        self.where = None
+
+    def record(self, stream):
+        self.where = len(stream.log)             # position in the log: what had been queued when it was recorded
+        stream.log.append(("record_event", stream.name))
+
     def synchronize(self):
         pass
 
@@ -176,7 +185,7 @@ class _FakeStream:
         self.log.append(("wait_stream", self.name, other.name))
 
     def wait_event(self, ev):
-        self.log.append(("wait_event", self.name))
+        self.log.append(("wait_event", self.name, ev.where))
 
     def record_event(self):
         self.log.append(("record_event", self.name))
@@ -213,6 +222,8 @@ def test_lanes_bookkeeping(fake_backend, monkeypatch):
             log.append(("new",))
             return _FakeStream(log, "lane%d" % (sum(1 for e in log if e[0] == "new") - 1))
 
+        Event = _FakeEvent
+
         @staticmethod
         def current_stream():
             return current[0]
@@ -248,6 +259,12 @@ def test_lanes_bookkeeping(fake_backend, monkeypatch):
     entered = [e[1] for e in log if e[0] == "enter"]
     assert entered[0] != entered[1] and entered == [entered[0], entered[1]] * 2 + [entered[0]]
     assert sum(1 for e in log if e[0] == "wait_stream") == 5      # every lane stream waits for the buffer's producer
+    # the Feeder recipe's hold: the current stream waits for the event recorded right behind the buffer's LOAD (its
+    # last reader), not for the end-of-buffer event -- that one would serialise the lanes through the next submit()
+    records = [i for i, e in enumerate(log) if e[0] == "record_event"]
+    assert len(records) == 2 * 5                                   # per buffer: behind the load, at the end
+    lanes.hold_current_stream(tickets[-1])
+    assert log[-1] == ("wait_event", "default", records[-2])
     for tk in reversed(tickets):
         assert lanes.result(tk, numpy_output=False).shape == (6, 8000, 2)
     with pytest.raises(KeyError):

@@ -5,7 +5,7 @@
 a=$1; b=$2; reps=${3:-6}; shift 3 || true
 for i in $(seq "$reps"); do
     for v in "$a" "$b"; do
-        ms=$(RCFM_LIB=$v python bench.py --steps 30 --warmup 5 --cpu-channels 0 --no-extras "$@" 2>/dev/null | grep -E -o '"ms_per_step": [0-9.]*' | cut -d' ' -f2)
+        ms=$(RCFM_LIB=$v python bench.py --steps 30 --warmup 5 --cpu-channels 0 --no-extras --no-pcie "$@" 2>/dev/null | grep -E -o '"ms_per_step": [0-9.]*' | head -1 | cut -d' ' -f2)
         echo "$(basename "$v") $ms"
     done
 done | sort | awk '{a[$1]=a[$1]" "$2; s[$1]+=$2; n[$1]++} END {for (k in a) printf "%s mean %.4f :%s\n", k, s[k]/n[k], a[k]}'

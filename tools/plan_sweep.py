@@ -15,14 +15,12 @@ def main(n):
     plans = [p for p in itertools.product(LENGTHS, repeat=3) if p[0] * p[1] * p[2] == n]
     res = []
     for p in plans:
-        env = dict(os.environ, RCFM_FFT_FORCE=",".join(map(str, p)))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_fft.py"), "%d:1" % n], env=env,
-                             capture_output=True, text=True).stdout
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_fft.py"), "%d:1" % n,
+                              "--plan", ",".join(map(str, p))], capture_output=True, text=True).stdout
         ms = [float(line.split()[3]) for line in out.splitlines() if "engine" in line]
         res.append((ms[0] if ms else float("inf"), p))
         print(p, ms, flush=True)
-    env = {k: v for k, v in os.environ.items() if k != "RCFM_FFT_FORCE"}
-    print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_fft.py"), "%d:1" % n], env=env,
+    print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_fft.py"), "%d:1" % n],
                          capture_output=True, text=True).stdout)
     print("best:", sorted(res)[:6])
 
