@@ -95,6 +95,12 @@ int rcfm_stream_destroy(void* stream);
  *             by one: a handle set that is rebuilt often should get a fresh arena)
  * Results do not depend on any of this.  bench.py --arena 1, tools/placement_sets.py. */
 int rcfm_arena_create(size_t block_bytes, rcfm_arena_t* out);
+/* The same over memory the HOST owns (a block of its own allocator -- a torch tensor, an rcfm_malloc block): the
+ * library's workspaces then live where the host decided, and two handle sets built one after the other inside arenas
+ * over the same block get the same addresses (tools/ab_libs.py compares two builds of the library that way, free of
+ * placement noise).  The memory must outlive the arena; it is not freed by rcfm_arena_destroy.  What does not fit comes
+ * from hipMalloc. */
+int rcfm_arena_adopt(void* base, size_t bytes, rcfm_arena_t* out);
 int rcfm_arena_bind(rcfm_arena_t arena);
 int rcfm_arena_stats(rcfm_arena_t arena, size_t* reserved_bytes, size_t* used_bytes, size_t* live_pieces);
 int rcfm_arena_destroy(rcfm_arena_t arena);
@@ -323,6 +329,8 @@ typedef struct rcfm_fft_plan {
     int32_t npass, fine_bits;
     int64_t tmp_stride; /* scratch elements per signal between passes (>= n) */
     rcfm_fft_pass pass[4];
+    int32_t tile_w;     /* lines per tile: 16, or 4 (two passes over ~3200-point tiles: cache-resident lengths) */
+    int32_t reserved;
 } rcfm_fft_plan;
 int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);
 /* Unnormalised forward (inverse = 0) or conjugate (inverse = 1) transform of `batch`

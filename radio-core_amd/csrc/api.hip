@@ -41,11 +41,13 @@ struct rcfm_arena_s {
     struct Block {
         char* base;
         size_t bytes, used;
+        bool owned;                         // false: the caller's memory (rcfm_arena_adopt)
     };
     std::vector<Block> blocks;
     size_t live = 0;                        // pieces handed out and not yet dropped
     ~rcfm_arena_s() {
-        for (auto& b : blocks) (void)hipFree(b.base);
+        for (auto& b : blocks)
+            if (b.owned) (void)hipFree(b.base);
     }
 };
 namespace rcfm {
@@ -70,7 +72,7 @@ void* arena_take(Arena* a, size_t bytes) {
     void* base = nullptr;
     const size_t sz = std::max(a->block_bytes, need);
     RC_HIP(hipMalloc(&base, sz));
-    a->blocks.push_back(Arena::Block{static_cast<char*>(base), sz, need});
+    a->blocks.push_back(Arena::Block{static_cast<char*>(base), sz, need, true});
     a->live += 1;
     return base;
 }
@@ -1162,8 +1164,21 @@ int rcfm_arena_create(size_t block_bytes, rcfm_arena_t* out) {
         if (block_bytes) {   // the first block now: its placement is the draw the caller asked for
             void* base = nullptr;
             RC_HIP(hipMalloc(&base, a->block_bytes));
-            a->blocks.push_back(Arena::Block{static_cast<char*>(base), a->block_bytes, 0});
+            a->blocks.push_back(Arena::Block{static_cast<char*>(base), a->block_bytes, 0, true});
         }
+        *out = a.release();
+    });
+}
+
+int rcfm_arena_adopt(void* base, size_t bytes, rcfm_arena_t* out) {
+    return guarded([&] {
+        RC_REQUIRE(out && base && bytes >= kArenaAlign, RCFM_ERR_ARG, "bad arena memory");
+        auto a = std::make_unique<Arena>();
+        a->block_bytes = (size_t)1 << 30;   // what does not fit the caller's memory comes from hipMalloc in 1 GiB blocks
+        char* p = static_cast<char*>(base);
+        const size_t skew = (kArenaAlign - (reinterpret_cast<uintptr_t>(p) & (kArenaAlign - 1))) & (kArenaAlign - 1);
+        RC_REQUIRE(bytes > skew + kArenaAlign, RCFM_ERR_ARG, "bad arena memory");
+        a->blocks.push_back(Arena::Block{p + skew, (bytes - skew) / kArenaAlign * kArenaAlign, 0, false});
         *out = a.release();
     });
 }

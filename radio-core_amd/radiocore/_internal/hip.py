@@ -45,6 +45,7 @@ SIGNATURES = {
     "rcfm_stream_create": [ctypes.POINTER(_vp)],
     "rcfm_stream_destroy": [_vp],
     "rcfm_arena_create": [_sz, ctypes.POINTER(_vp)],
+    "rcfm_arena_adopt": [_vp, _sz, ctypes.POINTER(_vp)],
     "rcfm_arena_bind": [_vp],
     "rcfm_arena_stats": [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)],
     "rcfm_arena_destroy": [_vp],
@@ -120,7 +121,7 @@ class FftPass(ctypes.Structure):
 class FftPlan(ctypes.Structure):
     """rcfm_fft_plan (include/rcfm.h)."""
     _fields_ = [("n", _i64), ("npass", ctypes.c_int32), ("fine_bits", ctypes.c_int32), ("tmp_stride", _i64),
-                ("passes", FftPass * 4)]
+                ("passes", FftPass * 4), ("tile_w", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _lib = None
@@ -268,9 +269,14 @@ class Arena:
 
     The arena must outlive those objects (close() refuses while their handles are alive).  No reference counterpart."""
 
-    def __init__(self, block_bytes=0):
+    def __init__(self, block_bytes=0, memory=None):
+        """memory: a device tensor the arena lives in instead of blocks of its own (rcfm_arena_adopt; kept alive here)."""
         h = _vp()
-        check(lib().rcfm_arena_create(_sz(int(block_bytes)), ctypes.byref(h)))
+        if memory is not None:
+            check(lib().rcfm_arena_adopt(ptr(memory), _sz(memory.numel() * memory.element_size()), ctypes.byref(h)))
+        else:
+            check(lib().rcfm_arena_create(_sz(int(block_bytes)), ctypes.byref(h)))
+        self._memory = memory
         self._handle = Handle(h, lib().rcfm_arena_destroy)
 
     @property

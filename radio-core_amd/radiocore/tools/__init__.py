@@ -9,3 +9,4 @@ from radiocore.tools.sharding import *
 from radiocore.tools.wire import *
 from radiocore.tools.feeder import *
 from radiocore.tools.lanes import *
+from radiocore.tools.arena import *

@@ -141,6 +141,12 @@ def _ring_worker(rank, world, port, kind, C, out_path):
         assert block.shape[0] == hi - lo
         gathered.append(sharding.gather_audio(torch.from_numpy(block), C, dst=0))
     dist.barrier()
+    np.save(out_path + ".slots%d.npy" % rank, np.array([ring.full_slots, ring.window_slots, ring.slot_bytes()]))
+    ring.drain()
+    ring.close()
+    # a window is attached no longer: the tuner loads and runs on its own storage again
+    tuner.load(dev[0])
+    assert tuner.run_all().shape[0] == hi - lo
     if rank == 0:
         np.save(out_path, np.stack([g.numpy() for g in gathered]))
     dist.destroy_process_group()
@@ -156,6 +162,12 @@ def test_rotating_fft_owner_equals_single_process(tmp_path, kind, C):
     out = str(tmp_path / "ring.npy")
     mp.spawn(_ring_worker, args=(2, _free_port(), kind, C, out), nprocs=2, join=True)
     got = np.load(out)
+    # each half of the band lies clear of the spectrum's ends: both ranks keep whole slots only for the buffers they own
+    # (two of the three in flight) and window-sized slots (rcfm_tuner_attach_window) for the others -- each window
+    # slot holds about half a spectrum here (two ranks); at eight ranks it is an eighth
+    for r in range(2):
+        full, win, nbytes = np.load(out + ".slots%d.npy" % r)
+        assert (full, win) == (2, 3) and 2 * 8 * N < nbytes < 4 * 8 * N, (r, full, win, nbytes)
     _paths()
     import radiocore as rc
     centres, bufs = _inputs(kind, C)

@@ -9,7 +9,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 # the traced process runs ONLY the headline path (--no-extras, no CPU baseline): 2 warm-up + 1 profile pass + 5 timed steps
-rocprofv3 --kernel-trace --stats -d "$out" -o run -- python "$root/bench.py" --steps 5 --warmup 2 --cpu-channels 0 --no-extras "$@" > "$out/bench.log" 2>&1 || true
+rocprofv3 --kernel-trace --stats -d "$out" -o run -- python "$root/bench.py" --steps 5 --warmup 2 --cpu-channels 0 --no-extras --no-pcie --placement-sets 1 "$@" > "$out/bench.log" 2>&1 || true
 db=$(find "$out" -name '*.db' | head -1)
 if [ -n "$db" ]; then
     python "$root/tools/rocpd_summary.py" "$db" --per-step 8 > "$root/gpurun_out/${tag}_kernel_stats.md"

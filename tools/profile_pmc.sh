@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter passes over one bench run (one rocprofv3 run per counter group, --kernel-trace only).
-#   tools/profile_pmc.sh <tag> -> gpurun_out/<tag>_pmc.txt
-tag=${1:-pmc}
+#   tools/profile_pmc.sh <tag> [bench.py arguments...] -> gpurun_out/<tag>_pmc.txt
+tag=${1:-pmc}; shift || true
 root=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 cd /tmp
@@ -14,7 +14,7 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
     i=$((i+1))
     out=$root/gpurun_out/$tag/g$i
     mkdir -p "$out"
-    rocprofv3 --kernel-trace --pmc $grp -d "$out" -o run --output-format csv -- python "$root/bench.py" --steps 1 --warmup 1 --cpu-channels 0 --no-extras > "$out/log.txt" 2>&1
+    rocprofv3 --kernel-trace --pmc $grp -d "$out" -o run --output-format csv -- python "$root/bench.py" --steps 1 --warmup 1 --cpu-channels 0 --no-extras --no-pcie --placement-sets 1 "$@" > "$out/log.txt" 2>&1
     csv=$(find "$out" -name '*counter_collection.csv' | head -1)
     echo "== $grp" >> "$root/gpurun_out/${tag}_pmc.txt"
     [ -n "$csv" ] && python "$root/tools/pmc_summary.py" "$csv" k_ >> "$root/gpurun_out/${tag}_pmc.txt" || tail -3 "$out/log.txt" >> "$root/gpurun_out/${tag}_pmc.txt"
