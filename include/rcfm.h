@@ -329,8 +329,6 @@ typedef struct rcfm_fft_plan {
     int32_t npass, fine_bits;
     int64_t tmp_stride; /* scratch elements per signal between passes (>= n) */
     rcfm_fft_pass pass[4];
-    int32_t tile_w;     /* lines per tile: 16, or 4 (two passes over ~3200-point tiles: cache-resident lengths) */
-    int32_t reserved;
 } rcfm_fft_plan;
 int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);
 /* Unnormalised forward (inverse = 0) or conjugate (inverse = 1) transform of `batch`

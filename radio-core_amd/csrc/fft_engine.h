@@ -56,8 +56,6 @@ struct FftPlanDesc {
     // pass reads, whole 128-byte lines even when n_2 is not a multiple of 16 (B = 240 000 = 480 x 500).
     int64_t tmp_stride;
     FftPass pass[kFftMaxPasses];
-    int tile_w;         // lines per tile: 16, or 4 for the two-pass plans over long tiles (fft_quad.hip)
-    int reserved;
 };
 
 // Factorises n (radices 2, 3, 4, 5, 6, 8, 10) into passes.  Returns false when n has
@@ -109,7 +107,6 @@ class FftEngine {
     static size_t lds_bytes(int L);
     static dim3 grid(const FftPass& p, int batch);
     static int compute_units();   // CUs of the current device (256 on MI355X)
-    int tile_w() const { return desc_.tile_w; }
 
    private:
     void build_tables();
@@ -118,10 +115,5 @@ class FftEngine {
     DeviceBuffer pos_[kFftMaxPasses];
     DeviceBuffer coarse_;
 };
-
-// One pass of a plan with tile_w == 4 (fft_quad.hip, the 4-line build of the tile kernels): plain load, plain / swapped /
-// row-window store.  `swap_in` / `swap_out`: the inverse transform by the swap identity.
-void quad_pass(const FftPassDev& dev, int batch, const float2* src, float2* dst, bool swap_in, bool swap_out, float scale,
-               const FftRowWindow* keep, int64_t n, hipStream_t stream);
 
 }  // namespace rcfm

@@ -29,7 +29,6 @@ bool choose_radices(int L, int* radix, int* nstages) {
     }
         RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
         RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
-        RCFM_FFT_QUAD_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
         default: break;
     }
@@ -57,17 +56,6 @@ bool is_fast_length(int64_t L) {
 #define RCFM_CASE(LEN, A, B, C, D) case LEN:
         RCFM_FFT_FAST_LENGTHS(RCFM_CASE)
         RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
-#undef RCFM_CASE
-        return true;
-        default: return false;
-    }
-}
-
-// Pass lengths of the 4-line build (fft_quad.hip).
-bool is_quad_length(int64_t L) {
-    switch (L) {
-#define RCFM_CASE(LEN, A, B, C, D) case LEN:
-        RCFM_FFT_QUAD_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
         return true;
         default: return false;
@@ -157,13 +145,11 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
     if (n < 256 || n >= (int64_t(1) << 32) || !smooth235(n)) return false;
     int np = 0;
     int64_t f[kFftMaxPasses];
-    bool quad = false;   // two passes over 4-line tiles of ~3200 points (cache-resident transforms)
     if (forced != nullptr) {
         if (nforced < 2 || nforced > kFftMaxPasses) return false;
-        quad = nforced == 2 && is_quad_length(forced[0]) && is_quad_length(forced[1]);
         int64_t prod = 1;
         for (int i = 0; i < nforced; ++i) {
-            if (forced[i] < 16 || (forced[i] > kFftBigL && !quad)) return false;
+            if (forced[i] < 16 || forced[i] > kFftBigL) return false;
             f[i] = forced[i];
             prod *= forced[i];
         }
@@ -200,7 +186,6 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
     FftPlanDesc d{};
     d.n = n;
     d.npass = np;
-    d.tile_w = quad ? 4 : kFftTileW;
     // fine angle below 0.03 rad: 2 pi F / n <= 0.03
     d.fine_bits = 0;
     while ((double)(int64_t(2) << d.fine_bits) * kTwoPi / (double)n <= 0.03) ++d.fine_bits;
@@ -364,11 +349,6 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
         const bool first = (t == 0), last = (t == np - 1);
         const float2* src = first ? in : mid(t - 1);
         const FftPassDev dev = pass_dev(t, first ? n : ts, last ? n : ts);
-        if (desc_.tile_w == 4) {   // two passes over 4-line tiles
-            quad_pass(dev, batch, src, last ? out : mid(t), first && inverse, last && inverse, last ? scale : 1.0f,
-                      last && !inverse ? keep : nullptr, n, stream);
-            continue;
-        }
         if (last) {
             LoadPlainT<false> ld{src};
             if (inverse)

@@ -661,7 +661,7 @@ constexpr bool triple_tile(int L) { return RCFM_FFT_TRIPLE400 && L == 400; }
 //                   arithmetic on the value; post(id, l, v) runs when the tile is consumed.
 // StoreOp contract: operator()(id, k, tile_base, off, v).
 template <int L, int R0, int R1, int R2, int R3, bool ROWS, int T, class LoadOp, class StoreOp>
-__global__ __launch_bounds__(T, ((W == 4 && L > kFftBigL) ? 4 : big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
+__global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile(FftPassDev d, LoadOp load,
                                                                                           StoreOp store) {
     // BIG: two 1024-thread workgroups per CU -- the tile is the whole LDS budget of the workgroup (80 KiB), so the
     // stage twiddles come from the table in global memory (twiddle_powers) and rows tiles use the XOR swizzle.
@@ -1577,9 +1577,6 @@ namespace fftk {
 // Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.  Two stages of radix 24..32 leave
 // 60 % of the 1024 threads idle and measured slower here (3.1 vs 2.75 ms at N = 2.4e8).
 #define RCFM_FFT_BIG_LENGTHS(X) X(600, 10, 10, 6, 1) X(625, 5, 5, 5, 5) X(640, 10, 8, 8, 1)
-// Long tiles of the 4-line build (tile_ns.h, fft_quad.hip): 100 KiB of LDS, one 1024-thread workgroup per CU.  The radix-25
-// stage of 3125 = 5^5 comes last, where there is no stage twiddle (25 powers of a table entry would not fit the registers).
-#define RCFM_FFT_QUAD_LENGTHS(X) X(3125, 5, 5, 5, 25) X(3200, 10, 8, 8, 5)
 #if RCFM_FFT_TWO_STAGE
 // Two stages wherever both keep at least ~60 % of the threads on a butterfly (L / R >= 10 rows of 16 lanes
 // for 256 threads, >= 19 for 512); 125 as 25 x 5 (5 rows) measured 4 % slower on cfg5.
@@ -1642,7 +1639,6 @@ namespace fftk {
 #define RCFM_FFT_600_THREADS 1024
 #endif
 constexpr int tile_threads(int L) {   // (RG = T / W butterfly rows per sweep is the same for every tile width)
-    if (W == 4 && L > kFftBigL) return 1024;   // the 4-line long tiles (fft_quad.hip): one workgroup per CU, 256 rows per sweep
     return (L == 600 ? RCFM_FFT_600_THREADS : (L > kFftMaxL || big_tile_pair(L)) ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256) *
            W / 16;
 }
@@ -1673,7 +1669,6 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
                           d.p.n_o1 * d.p.n_o2 <= 65535 && batch <= 65535;
     if (shape_ok) {
         const dim3 grid((unsigned)((d.p.n_inner + W - 1) / W), (unsigned)(d.p.n_o1 * d.p.n_o2), (unsigned)batch);
-        if constexpr (W != 4)   // (the 4-line build holds the long tiles only)
         switch (d.p.L) {
 #define RCFM_CASE(LEN, A, B, C, D)                                                                            \
     case LEN:                                                                                                 \
@@ -1692,12 +1687,6 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
         if constexpr (W == 16 && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
             switch (d.p.L) {
                 RCFM_FFT_BIG_LENGTHS(RCFM_CASE)
-                default: break;
-            }
-        }
-        if constexpr (W == 4 && is_plain_functor<LoadOp>::value && is_plain_functor<StoreOp>::value) {
-            switch (d.p.L) {
-                RCFM_FFT_QUAD_LENGTHS(RCFM_CASE)
                 default: break;
             }
         }

@@ -17,14 +17,6 @@
 #define RCFM_NS_OPEN
 #define RCFM_NS_CLOSE
 #define RCFM_NARROW_BUILD 0
-#elif RCFM_TILE_W == 4
-// A third build, for ONE purpose: two-pass plans of transforms that live in the 256 MiB Infinity Cache (N = 1e7 =
-// 3125 x 3200, the reference's own Tuner benchmark length, tests/benchmark.py:105).  A pass length of ~3200 points only
-// fits the LDS as 4 lines per tile (100 KiB, one 1024-thread workgroup per CU); the 32-byte row segments that would
-// starve on HBM are cache hits here, and the transform saves one of its three passes (fft_quad.hip).
-#define RCFM_NS_OPEN namespace quad {
-#define RCFM_NS_CLOSE }
-#define RCFM_NARROW_BUILD 1
 #else
 #define RCFM_NS_OPEN namespace narrow {
 #define RCFM_NS_CLOSE }

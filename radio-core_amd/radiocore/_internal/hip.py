@@ -121,7 +121,7 @@ class FftPass(ctypes.Structure):
 class FftPlan(ctypes.Structure):
     """rcfm_fft_plan (include/rcfm.h)."""
     _fields_ = [("n", _i64), ("npass", ctypes.c_int32), ("fine_bits", ctypes.c_int32), ("tmp_stride", _i64),
-                ("passes", FftPass * 4), ("tile_w", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("passes", FftPass * 4)]
 
 
 _lib = None

@@ -144,17 +144,3 @@ def test_plan_entry_refuses_lengths_that_do_not_multiply_to_n():
     x = hip.empty((240000,), torch.complex64)
     lens = (ctypes.c_int64 * 2)(480, 480)
     assert lib.rcfm_fft_c2c_plan(240000, lens, 2, 1, 0, hip.ptr(x), hip.ptr(x), hip.stream()) != 0
-
-
-@pytest.mark.parametrize("plan", [(3125, 3200), (3200, 3125)])
-def test_two_pass_plan_over_four_line_tiles(plan):
-    """N = 1e7 (the reference's own Tuner benchmark length, tests/benchmark.py:105) as TWO passes over 4-line tiles of
-    3125 / 3200 points (csrc/fft_quad.hip) instead of three passes over 16-line tiles: both orders, forward against
-    numpy and the round trip."""
-    n = 10_000_000
-    r = np.random.default_rng(7)
-    x = (r.standard_normal((1, n)) + 1j * r.standard_normal((1, n))).astype(np.complex64)
-    want = np.fft.fft(x.astype(np.complex128), axis=1).astype(np.complex64)
-    got = _run_plan(n, plan, 1, False, x)
-    assert rel_err(got, want) <= 2e-6
-    assert rel_err(_run_plan(n, plan, 1, True, want), x * n) <= 4e-6
