@@ -377,11 +377,18 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
 
     const int last = n32 - 1;
     const int o = tid * PER;
-    if (interior) {   // m leaves as 16-byte stores like p
-        float4* dst = reinterpret_cast<float4*>(m_out + (int64_t)c * n + t0 + o);
-        const v2f* src = reinterpret_cast<const v2f*>(&m_s[mpos(H + o)]);   // H + o is a multiple of 8
-        dst[0] = make_float4(src[0].x, src[0].y, src[1].x, src[1].y);
-        dst[1] = make_float4(src[2].x, src[2].y, src[3].x, src[3].y);
+    // Stores leave LANE-CONTIGUOUS: a wave owns 512 consecutive outputs and each of its two store instructions writes
+    // 64 x 16 bytes = eight whole 128-byte lines (lane l: outputs 4 l .. 4 l + 3 of the wave's first / second half).
+    // With each thread storing its own 8 outputs as two float4s, every line was completed by two instructions and the
+    // L2 had to merge the halves.
+    const int wbase = (tid >> 6) * (64 * PER), lane4 = (tid & 63) * 4;
+    if (interior) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = wbase + h * (32 * PER) + lane4;                    // H + pos is a multiple of 4: one 8-group
+            const v2f* src = reinterpret_cast<const v2f*>(&m_s[mpos(H + pos)]);
+            *reinterpret_cast<float4*>(m_out + (int64_t)c * n + t0 + pos) = make_float4(src[0].x, src[0].y, src[1].x, src[1].y);
+        }
     }
     // Edge tiles (scipy filtfilt, padtype="odd", bandpass.py:72): the odd reflection of m about the first / last sample is
     // written INTO the LDS window -- m[q] = 2 m[0] - m[-q] for q < 0, 2 m[last] - m[2 last - q] for last < q <= last + H --
@@ -438,7 +445,21 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
                 wo[0] = wpair(H - 1 - j);
             }
         }
-        if (inner_tile || t0 + o + PER <= n32) {
+        if (inner_tile || t0 + T <= n32) {   // (workgroup-uniform) the whole tile lies inside the channel
+            // through d_s (dead since m_s was built): thread order in, lane-contiguous order out
+            float4* stage = reinterpret_cast<float4*>(&d_s[o]);
+            stage[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
+            stage[1] = make_float4(acc[4].x + acc[4].y, acc[5].x + acc[5].y, acc[6].x + acc[6].y, acc[7].x + acc[7].y);
+            // a wave reads back only what its own lanes staged ([wbase, wbase + 512)), and the LDS serves one wave's
+            // accesses in order: no workgroup barrier, the writes only have to be issued before the reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pos = wbase + h * (32 * PER) + lane4;
+                *reinterpret_cast<float4*>(p_out + (int64_t)c * n + t0 + pos) = *reinterpret_cast<const float4*>(&d_s[pos]);
+            }
+        } else if (t0 + o + PER <= n32) {
             float4* dst = reinterpret_cast<float4*>(p_out + (int64_t)c * n + t0 + o);
             dst[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
             dst[1] = make_float4(acc[4].x + acc[4].y, acc[5].x + acc[5].y, acc[6].x + acc[6].y, acc[7].x + acc[7].y);
@@ -728,7 +749,7 @@ __global__ __launch_bounds__(kThreads) void k_fir51(const float* __restrict__ x,
             acc[r] = (t < -0.999f) ? -0.999f : ((t > 0.999f) ? 0.999f : t);   // NaN stays NaN like np.clip
         }
     }
-    if (e0 + PER <= total) {
+    if (e0 + PER <= total) {   // (lane-contiguous stores through LDS, as in the pilot stage, cost this small kernel 7 %: two more barriers)
         float4* dst = reinterpret_cast<float4*>(yc + e0);
         dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
