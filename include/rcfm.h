@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RCFM_VERSION 100 /* 0.1.0 */
+#define RCFM_VERSION 101 /* 0.1.1: rcfm_fft_pass grew in_t / out_t */
 
 typedef enum rcfm_status {
     RCFM_OK = 0,
@@ -323,6 +323,8 @@ typedef struct rcfm_fft_pass {
     int64_t out_o1, out_o2, out_i, out_k;
     int64_t tw_o1, tw_o2, tw_i;
     int32_t has_twiddle, load_along_l;
+    int64_t in_t, out_t; /* tile-blocked hand-over between strided passes: element offset of tile t (16 lines) = t * in_t /
+                            t * out_t; 0 = the plain layout (16 * in_i, 16) */
 } rcfm_fft_pass;
 typedef struct rcfm_fft_plan {
     int64_t n;
@@ -331,6 +333,10 @@ typedef struct rcfm_fft_plan {
     rcfm_fft_pass pass[4];
 } rcfm_fft_plan;
 int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);
+/* The plan for given pass lengths (what rcfm_fft_c2c_plan runs).  blocked: the tile-blocked hand-over between the first two
+ * passes of a three-pass plan: -1 = as the engine decides (transforms beyond the Infinity Cache), 0 = never, 1 = whenever
+ * the lengths allow it (tests/test_fft_plan.py models it at small n). */
+int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int blocked, rcfm_fft_plan* plan);
 /* Unnormalised forward (inverse = 0) or conjugate (inverse = 1) transform of `batch`
  * contiguous length-n complex64 signals; in == out allowed.  (scipy.fft.fft / ifft*n) */
 int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);

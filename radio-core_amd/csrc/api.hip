@@ -2052,6 +2052,16 @@ int rcfm_fft_describe(int64_t n, int max_l, rcfm_fft_plan* plan) {
     });
 }
 
+int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int blocked, rcfm_fft_plan* plan) {
+    return guarded([&] {
+        RC_REQUIRE(plan != nullptr && pass_lengths != nullptr, RCFM_ERR_ARG, "NULL argument");
+        FftPlanDesc d;
+        RC_REQUIRE(fft_plan_describe(n, &d, 0, pass_lengths, npass, blocked), RCFM_ERR_ARG,
+                   "pass lengths not supported by the FFT engine");
+        std::memcpy(plan, &d, sizeof(d));
+    });
+}
+
 int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, void* stream) {
     return guarded([&] {
         RC_REQUIRE(in && out && batch >= 1, RCFM_ERR_ARG, "bad argument");

@@ -45,6 +45,11 @@ struct FftPass {
     int64_t tw_o1, tw_o2, tw_i;
     int has_twiddle;
     int load_along_l;   // 1: a line is contiguous in memory (in_l == 1): lanes run along l when loading
+    // Tile-blocked hand-over between two strided passes (0 = the plain layout, where tile t of 16 lines starts 16 in_i /
+    // 16 elements after tile t - 1): tile t starts at t * in_t / t * out_t.  The first pass of a transform that does not
+    // fit the Infinity Cache writes each of its tiles as ONE contiguous run (out_t = 16 L, out_k = 16) instead of L
+    // segments a row pitch of megabytes apart, and the second pass reads that layout (fft_engine.hip).
+    int64_t in_t, out_t;
 };
 
 struct FftPlanDesc {
@@ -63,8 +68,10 @@ struct FftPlanDesc {
 // fall back to rocFFT.
 // max_l (<= kFftMaxL, 0 = default) caps the per-pass length; tests use it to force deep plans.
 // `forced` (nforced factors whose product is n) overrides the planner's choice of pass lengths.
+// `blocked`: the tile-blocked hand-over between the first two passes of a three-pass plan (FftPass::out_t): -1 = when
+// the transform does not fit the Infinity Cache (the default), 0 = never, 1 = whenever the lengths allow it (tests).
 bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l = 0, const int64_t* forced = nullptr,
-                       int nforced = 0);
+                       int nforced = 0, int blocked = -1);
 
 // Device-side view of one pass, handed to the kernel by value.
 struct FftPassDev {

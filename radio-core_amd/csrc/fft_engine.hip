@@ -137,9 +137,14 @@ bool split(int64_t n, int np, int max_l, int64_t* f, double* best_cost = nullptr
 
 constexpr bool big_tiles_enabled() { return true; }
 
+// Three-pass plans that hand the first pass's output over tile by tile (fft_plan_describe).
+bool hand_over_blocked(int64_t n, const int64_t* f, bool any_size) {
+    return (any_size || (size_t)n * sizeof(float2) > ((size_t)256 << 20)) && f[2] % 16 == 0 && (f[1] * f[2]) % 16 == 0;
+}
+
 }  // namespace
 
-bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* forced, int nforced) {
+bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* forced, int nforced, int blocked) {
     const bool default_cap = (max_l <= 0);
     if (max_l <= 0 || max_l > kFftMaxL) max_l = kFftMaxL;
     if (n < 256 || n >= (int64_t(1) << 32) || !smooth235(n)) return false;
@@ -239,6 +244,20 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
             p.has_twiddle = 0;
             p.load_along_l = 1;
         }
+    }
+    // Transforms of three passes that do not fit the 256 MiB Infinity Cache: the first pass hands its output to the second
+    // tile by tile -- tile a of 16 lines j (j = l_2 n_3 + j_2, whole tiles inside one l_2 because n_3 is a multiple of 16) is
+    // ONE contiguous run of 16 n_1 points, [a][k_1][16], instead of n_1 segments a row pitch of megabytes apart; the second
+    // pass (block k_1, lines j_2, points l_2) finds point l_2 of its tile j_2 / 16 at ((l_2 n_3 / 16 + j_2 / 16) n_1 + k_1) 16.
+    // Placement decides how fast a pass WRITES at a pitch of megabytes (profiles/r04_k_placement.md: 20 % between buffer
+    // pairs); reads at such a pitch are the less sensitive side.  Same-address A/B at N = 2.4e8: 2.302 -> 2.260 ms
+    // (profiles/r05_k_blocked_handover.txt; the non-temporal stores beat sc1 ones again once the runs are contiguous).
+    if (np == 3 && blocked != 0 && hand_over_blocked(n, f, blocked > 0)) {
+        d.pass[0].out_t = 16 * f[0];
+        d.pass[0].out_k = 16;
+        d.pass[1].in_t = 16 * f[0];
+        d.pass[1].in_o1 = 16;
+        d.pass[1].in_l = f[2] * f[0];
     }
     d.tmp_stride = n;
     if (np == 2 && (f[1] % 16) != 0) {
@@ -362,10 +381,6 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<false>{out, scale}, stream);
         } else {
             StorePlainT<false> st{mid(t), 1.0f};
-            if (first && !inverse && ping_pong) {   // rows megabytes apart: sc1 stores (fft_kernel.h, StorePlainSc1)
-                launch_fft_pass<kStridedOnly>(dev, batch, LoadPlainT<false>{src}, StorePlainSc1{mid(t), 1.0f}, stream);
-                continue;
-            }
             if (first && inverse)
                 launch_fft_pass<kStridedOnly>(dev, batch, LoadPlainT<true>{src}, st, stream);
             else

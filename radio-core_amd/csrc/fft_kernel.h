@@ -398,8 +398,10 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
     id.o1 = t / p.n_o2;
     const int64_t i0 = ti * W;
     const int wvalid = (int)((p.n_inner - i0) < W ? (p.n_inner - i0) : W);
-    const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + i0 * p.in_i;
-    const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0 * p.out_i;
+    const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 +
+                            (p.in_t ? ti * p.in_t : i0 * p.in_i);
+    const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 +
+                             (p.out_t ? ti * p.out_t : i0 * p.out_i);
     const int swz = p.load_along_l ? (W - 1) : 0;
 
     for (int e = tid; e < L; e += kThreads) {
@@ -692,8 +694,11 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
     // Lanes past the end of a row (last tile only) load line 0 of the tile again and are never stored:
     // every lane transforms its own line, so nothing has to be masked in between.
     const int wvalid = left < W ? left : W;
-    const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 + (int64_t)i0 * p.in_i;
-    const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 + i0;
+    // (tile-blocked hand-over between strided passes: FftPass::in_t / out_t, 0 = the plain layout)
+    const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 +
+                            (p.in_t ? (int64_t)bp.tile * p.in_t : (int64_t)i0 * p.in_i);
+    const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 +
+                             (p.out_t ? (int64_t)bp.tile * p.out_t : (int64_t)i0);
     const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
 
     // ---- global loads: all issued before anything waits -----------------------------------
@@ -1492,11 +1497,6 @@ __device__ __forceinline__ void stream_store(float2* p, float2 v) {
 #endif
 }
 
-// A store with the sc1 cache-policy bit (system-coherent scope one: written through the XCD's L2 towards memory).
-__device__ __forceinline__ void sc1_store(float2* p, float2 v) {
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-
 template <bool SWAP>
 struct LoadPlainT {
     const float2* in;
@@ -1515,19 +1515,6 @@ struct StorePlainT {
     __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
         stream_store(out + base + off,
                      SWAP ? make_float2(v.y * scale, v.x * scale) : make_float2(v.x * scale, v.y * scale));
-    }
-};
-
-// StorePlainT<false> with sc1 instead of non-temporal stores: the first pass of a transform that does not fit the
-// Infinity Cache, whose rows are megabytes apart (N = 2.4e8: 3.2 MB).  +1.9 % on the tile copy of that shape
-// (profiles/r04_k_store_flavours.txt), -14 us of the wideband FFT in the product (same-address A/B,
-// profiles/r05_b_kernel_ab.txt); on the LAST pass, where half of the segments straddle lines, sc1 and plain stores lose
-// 0.4 - 0.8 % to nt (same file).
-struct StorePlainSc1 {
-    float2* out;
-    float scale;
-    __device__ __forceinline__ void operator()(const LineId&, int, int64_t base, unsigned off, float2 v) const {
-        sc1_store(out + base + off, make_float2(v.x * scale, v.y * scale));
     }
 };
 
@@ -1648,7 +1635,6 @@ template <class T> struct is_plain_functor : std::false_type {};
 template <bool S> struct is_plain_functor<LoadPlainT<S>> : std::true_type {};
 template <bool S> struct is_plain_functor<StorePlainT<S>> : std::true_type {};
 template <> struct is_plain_functor<StoreRowWindow> : std::true_type {};
-template <> struct is_plain_functor<StorePlainSc1> : std::true_type {};
 
 // Which pass kinds a functor pair is ever used with (prunes template instantiations).
 enum PassKinds : int { kAnyPass = 0, kStridedOnly = 1, kRowsOnly = 2 };

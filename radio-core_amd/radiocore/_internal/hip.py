@@ -97,6 +97,7 @@ SIGNATURES = {
     "rcfm_pll_phase": [_vp, _sz, _dbl, _i, _vp, _vp],
     "rcfm_discriminator": [_i, _i, _vp, _vp, _vp],
     "rcfm_fft_describe": [_i64, _i, _vp],
+    "rcfm_fft_describe_plan": [_i64, ctypes.POINTER(_i64), _i, _i, _vp],
     "rcfm_fft_c2c": [_i64, _i, _i, _vp, _vp, _vp],
     "rcfm_fft_c2c_plan": [_i64, ctypes.POINTER(_i64), _i, _i, _i, _vp, _vp, _vp],
     "rcfm_fft_c2c_rocfft": [_i64, _i, _i, _vp, _vp, _vp],
@@ -115,7 +116,7 @@ class FftPass(ctypes.Structure):
                 ("in_o1", _i64), ("in_o2", _i64), ("in_i", _i64), ("in_l", _i64),
                 ("out_o1", _i64), ("out_o2", _i64), ("out_i", _i64), ("out_k", _i64),
                 ("tw_o1", _i64), ("tw_o2", _i64), ("tw_i", _i64),
-                ("has_twiddle", ctypes.c_int32), ("load_along_l", ctypes.c_int32)]
+                ("has_twiddle", ctypes.c_int32), ("load_along_l", ctypes.c_int32), ("in_t", _i64), ("out_t", _i64)]
 
 
 class FftPlan(ctypes.Structure):

@@ -20,6 +20,16 @@ def describe(n, max_l=0):
     return plan if rc == 0 else None
 
 
+def describe_plan(n, lengths, blocked=-1):
+    """The plan for given pass lengths (rcfm_fft_describe_plan); blocked = 1 forces the tile-blocked hand-over."""
+    from radiocore._internal import hip
+    lib = hip.load_library()
+    plan = hip.FftPlan()
+    arr = (ctypes.c_int64 * len(lengths))(*lengths)
+    rc = lib.rcfm_fft_describe_plan(ctypes.c_int64(n), arr, len(lengths), int(blocked), ctypes.byref(plan))
+    return plan if rc == 0 else None
+
+
 def lds_fft(tile, radices):
     """tile: [L, w] complex; in-place DIF stages, then read-out through pos[]."""
     L = tile.shape[0]
@@ -59,7 +69,11 @@ def run_pass(p, n, src, dst):
                 wv = min(W, p.n_inner - i0)
                 i = i0 + np.arange(wv)
                 l = np.arange(L)
-                in_addr = o1 * p.in_o1 + o2 * p.in_o2 + i[None, :] * p.in_i + l[:, None] * p.in_l
+                # tile-blocked hand-over (in_t / out_t != 0): tile t of 16 lines starts at t * in_t, lanes follow at in_i
+                lane = np.arange(wv)
+                tile_in = (i0 // W) * p.in_t + lane * p.in_i if p.in_t else i * p.in_i
+                tile_out = (i0 // W) * p.out_t + lane * p.out_i if p.out_t else i * p.out_i
+                in_addr = o1 * p.in_o1 + o2 * p.in_o2 + tile_in[None, :] + l[:, None] * p.in_l
                 tile = src[in_addr]
                 out = lds_fft(tile, radices)
                 k = np.arange(L)
@@ -68,7 +82,7 @@ def run_pass(p, n, src, dst):
                     e = line[None, :] * k[:, None]
                     assert e.max() < n                              # the kernel relies on this: no modulo
                     out = out * np.exp(-2j * np.pi * e / n)
-                out_addr = o1 * p.out_o1 + o2 * p.out_o2 + i[None, :] * p.out_i + k[:, None] * p.out_k
+                out_addr = o1 * p.out_o1 + o2 * p.out_o2 + tile_out[None, :] + k[:, None] * p.out_k
                 dst[out_addr] = out
 
 

@@ -52,7 +52,7 @@ def test_binding_table_matches_header():
 
 def test_version_and_error_string(lib):
     lib.rcfm_version.restype = ctypes.c_int
-    assert lib.rcfm_version() == 100
+    assert lib.rcfm_version() == 101
     lib.rcfm_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.rcfm_last_error(), bytes)
 

@@ -57,3 +57,29 @@ def test_deep_plans(n, max_l, npass):
     got = fft_model.model_fft(x, plan)
     want = np.fft.fft(x)
     assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("lengths", [(20, 25, 32), (16, 20, 48), (64, 16, 16)])
+def test_tile_blocked_hand_over_between_the_first_two_passes(lengths):
+    """Three-pass plans of transforms beyond the Infinity Cache let the first pass write every tile as ONE contiguous run
+    ([tile][k_1][16]) and the second pass read that layout (FftPass::out_t / in_t).  Forced here at model sizes: the
+    blocked plan is an FFT, its intermediate really is tile-contiguous, and the plain plan of the same lengths is not."""
+    n = lengths[0] * lengths[1] * lengths[2]
+    plain = fft_model.describe_plan(n, lengths, blocked=0)
+    blocked = fft_model.describe_plan(n, lengths, blocked=1)
+    assert plain is not None and blocked is not None
+    assert plain.passes[0].out_t == 0 and plain.passes[1].in_t == 0
+    p0, p1 = blocked.passes[0], blocked.passes[1]
+    assert p0.out_t == 16 * lengths[0] and p0.out_k == 16 and p1.in_t == p0.out_t and p1.in_o1 == 16
+    assert p1.in_l == lengths[2] * lengths[0]
+    r = np.random.default_rng(n)
+    x = r.standard_normal(n) + 1j * r.standard_normal(n)
+    want = np.fft.fft(x)
+    for plan in (plain, blocked):
+        got = fft_model.model_fft(x, plan)
+        assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+    # the default (by size) leaves small transforms plain, and lengths whose third factor is not a multiple of 16 too
+    assert fft_model.describe_plan(n, lengths, blocked=-1).passes[0].out_t == 0
+    assert fft_model.describe_plan(20 * 32 * 25, (20, 32, 25), blocked=1).passes[0].out_t == 0
+    big = fft_model.describe(240_000_000)
+    assert big.passes[0].out_t == 16 * 600 and big.passes[1].in_l == 640 * 600

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import provenance  # noqa: E402
 
 STAGES = [   # (stage of rcfm_profile_*, regex on the kernel name); first match wins
-    ("tuner_fft_N", r"k_fft_tile<(600|625|640),.*LoadPlainT<false>, (StorePlainT<false>|StorePlainSc1|StoreRowWindow)"),
+    ("tuner_fft_N", r"k_fft_tile<(600|625|640),.*LoadPlainT<false>, (StorePlainT<false>|StoreRowWindow)"),
     ("tuner_ifft_B", r"LoadTunerGather|StorePhase"),
     ("pilot_stage", r"k_pilot_stage"),
     ("rfft_B", r"LoadRealPair|LoadPhaseStepPair"),
