@@ -13,10 +13,6 @@ __device__ __forceinline__ float atan2_over_pi(float y, float x) {
     const float a = mn * __builtin_amdgcn_rcpf(mx);
     const float t = a * a;
     // the polynomial's coefficients carry the 1 / pi (max error 3.7e-8 in units of pi against 4.2e-8 with a final multiply)
-#ifndef RCFM_ATAN_DEGREE
-#define RCFM_ATAN_DEGREE 17
-#endif
-#if RCFM_ATAN_DEGREE == 17
     float p = 0.0007893929141573608f;
     p = fmaf(p, t, -0.0046154772862792015f);
     p = fmaf(p, t, 0.012717602774500847f);
@@ -26,24 +22,6 @@ __device__ __forceinline__ float atan2_over_pi(float y, float x) {
     p = fmaf(p, t, 0.06361839175224304f);
     p = fmaf(p, t, -0.10610104352235794f);
     p = fmaf(p, t, 0.31830984354019165f);
-#elif RCFM_ATAN_DEGREE == 13   // 1.1e-7 in units of pi (timing experiments: profiles/r03_e_atan_degree.md)
-    float p = 0.002161841284429284f;
-    p = fmaf(p, t, -0.01067262740209221f);
-    p = fmaf(p, t, 0.025310043404368533f);
-    p = fmaf(p, t, -0.04209787029617434f);
-    p = fmaf(p, t, 0.06304108107705708f);
-    p = fmaf(p, t, -0.10605095526635636f);
-    p = fmaf(p, t, 0.31830856631722476f);
-#elif RCFM_ATAN_DEGREE == 11   // 5.7e-7 in units of pi
-    float p = -0.003719796037551087f;
-    p = fmaf(p, t, 0.016724280961288925f);
-    p = fmaf(p, t, -0.037018901156121074f);
-    p = fmaf(p, t, 0.06158344143096178f);
-    p = fmaf(p, t, -0.10587178119171209f);
-    p = fmaf(p, t, 0.3183022244864759f);
-#else
-#error "RCFM_ATAN_DEGREE: 17, 13 or 11"
-#endif
     float r = p * a;                                // [0, 1/4]
     r = (ay > ax) ? 0.5f - r : r;                  // [0, 1/2]
     r = (x < 0.f) ? 1.f - r : r;                   // [0, 1]

@@ -252,7 +252,7 @@ inline bool fft_tile2_decim_rt_applies(const FftPassDev& d1, const FftPassDev& d
     RCFM_FFT_DECIM_RT_LENGTHS(RCFM_CASE)
 #undef RCFM_CASE
     const int L2 = d2.p.L;
-    if (!have || !RCFM_FFT_TWO_STAGE || (L2 & 1) || L2 < 16 || L2 >= d1.p.L) return false;
+    if (!have || (L2 & 1) || L2 < 16 || L2 >= d1.p.L) return false;
     for (int s = 0; s < d2.p.nstages; ++s)
         if (!decim_rt_radix_ok(d2.p.radix[s])) return false;
     return d1.p.load_along_l && !d2.p.load_along_l && d1.p.n_inner == d2.p.n_inner &&

@@ -35,101 +35,58 @@ constexpr int kLogW = W == 16 ? 4 : W == 8 ? 3 : 2;
 static_assert((1 << kLogW) == W, "tile width: 4, 8 or 16 lines");
 constexpr int kThreads = 256 * W / 16;
 
-// Complex product.  RCFM_ASM_CMUL: two packed instructions whose op_sel / neg modifiers pick the
+// Complex product: two packed instructions whose op_sel / neg modifiers pick the
 // halves (a.x b, then a.y (-b.y, b.x) + ...) -- the compiler's own packing builds those operand
 // pairs with v_mov's (19 % of the tile kernel's VALU instructions).
-#ifndef RCFM_ASM_CMUL
-#define RCFM_ASM_CMUL 1
-#endif
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-#if RCFM_ASM_CMUL
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f A, B, D;
     A.x = a.x; A.y = a.y; B.x = b.x; B.y = b.y;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(D) : "v"(A), "v"(B));
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(D) : "v"(A), "v"(B));
     return make_float2(D.x, D.y);
-#else
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-#endif
 }
-// RCFM_CADD_MODE: 0 = left to the compiler (which packs some of these into v_pk_add_f32 and pays for the operand
-// pairs with v_mov), 1 = always one v_pk_add_f32 on aligned register pairs, 2 = always two scalar adds.
-#ifndef RCFM_CADD_MODE
-#define RCFM_CADD_MODE 1   // cfg4 7.368 -> 7.332 ms (five alternations on one box); the tuner's last pass loses 69 of 819 scalar VALU instructions
-#endif
+// Complex add / subtract: always ONE v_pk_add_f32 on aligned register pairs (left to the compiler, some were packed and
+// paid for their operand pairs with v_mov: cfg4 -0.5 %, the tuner's last pass lost 69 of 819 scalar VALU instructions).
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) {
-#if RCFM_CADD_MODE == 1
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f A, B, D;
     A.x = a.x; A.y = a.y; B.x = b.x; B.y = b.y;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(D) : "v"(A), "v"(B));
     return make_float2(D.x, D.y);
-#elif RCFM_CADD_MODE == 2
-    float x, y;
-    asm("v_add_f32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
-    asm("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
-    return make_float2(x, y);
-#else
-    return make_float2(a.x + b.x, a.y + b.y);
-#endif
 }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) {
-#if RCFM_CADD_MODE == 1
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f A, B, D;
     A.x = a.x; A.y = a.y; B.x = b.x; B.y = b.y;
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(D) : "v"(A), "v"(B));
     return make_float2(D.x, D.y);
-#elif RCFM_CADD_MODE == 2
-    float x, y;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(x) : "v"(a.x), "v"(b.x));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(y) : "v"(a.y), "v"(b.y));
-    return make_float2(x, y);
-#else
-    return make_float2(a.x - b.x, a.y - b.y);
-#endif
 }
 // multiply by -i / +i
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
 __device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }
 // t + (-i) u and t + (+i) u in one packed add (half-swap and sign via op_sel / neg_hi / neg_lo).
 __device__ __forceinline__ float2 cadd_mi(float2 t, float2 u) {
-#if RCFM_ASM_CMUL
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f T, U, D;
     T.x = t.x; T.y = t.y; U.x = u.x; U.y = u.y;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(D) : "v"(T), "v"(U));
     return make_float2(D.x, D.y);
-#else
-    return make_float2(t.x + u.y, t.y - u.x);
-#endif
 }
 __device__ __forceinline__ float2 cadd_pi(float2 t, float2 u) {
-#if RCFM_ASM_CMUL
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f T, U, D;
     T.x = t.x; T.y = t.y; U.x = u.x; U.y = u.y;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(D) : "v"(T), "v"(U));
     return make_float2(D.x, D.y);
-#else
-    return make_float2(t.x - u.y, t.y + u.x);
-#endif
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (global loads and
 // stores share that counter on gfx9): in the multi-transform tile kernels that would wait, at every
 // stage boundary, for the point-wise stage's prefetched inputs and for the stores of the transform just
 // finished.  LDS hand-offs only need lgkmcnt(0) + s_barrier.
-#ifndef RCFM_LDS_BARRIER
-#define RCFM_LDS_BARRIER 1
-#endif
 __device__ __forceinline__ void lds_barrier() {
-#if RCFM_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 
 // ---- small forward DFTs, y[q'] = sum_q x[q] exp(-2 pi i q q' / R), in place --------
@@ -481,15 +438,10 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
 // each XCD has its own L2.  Neighbouring tiles of a row share 128-byte lines whenever a functor reads
 // 64-byte or unaligned segments (real inputs, the tuner's rolled spectrum); mapping x -> tile so that
 // each XCD owns a contiguous eighth of the row lets the second reader hit the first one's L2 line.
-#ifndef RCFM_FFT_XCD_ORDER
-#define RCFM_FFT_XCD_ORDER 1
-#endif
 // Rows of at most this many tiles go to the XCDs as WHOLE rows instead: the blocks of eight consecutive signals form
 // one group, and XCD k takes every tile of the group's k-th signal (an eighth of a short row is one or two tiles --
 // with 8 tiles per row, cfg5's B = 12 500, every neighbour sat on another XCD and each shared line came from HBM twice).
-#ifndef RCFM_FFT_XCD_GROUP_MAX
-#define RCFM_FFT_XCD_GROUP_MAX 15
-#endif
+constexpr unsigned kXcdGroupMax = 15;
 struct BlockPos {
     unsigned tile, batch;
 };
@@ -504,8 +456,7 @@ __device__ __forceinline__ BlockPos block_pos(const VBlock& vb);
 __device__ __forceinline__ BlockPos block_pos() { return block_pos(vblock_hw()); }
 __device__ __forceinline__ BlockPos block_pos(const VBlock& vb) {
     const unsigned gx = vb.gx, x = vb.x, z = vb.z;
-#if RCFM_FFT_XCD_ORDER
-    if (gx <= RCFM_FFT_XCD_GROUP_MAX) {
+    if (gx <= kXcdGroupMax) {
         // linear workgroup id = x + gx (y + gy z); with gy = 1 and z0 = z & ~7 its low three bits are those of
         // q = x + gx (z & 7), the position inside the group: XCD (q & 7) takes signal z0 + (q & 7), tile q >> 3
         if (vb.gy == 1 && (z | 7u) < vb.gz) {
@@ -515,9 +466,6 @@ __device__ __forceinline__ BlockPos block_pos(const VBlock& vb) {
         return BlockPos{x, z};
     }
     return BlockPos{(gx & 7u) ? x : (x & 7u) * (gx >> 3) + (x >> 3), z};
-#else
-    return BlockPos{x, z};
-#endif
 }
 
 // Small DFTs that leave output q' in slot perm<R>(q') (no register shuffling afterwards).
@@ -578,20 +526,16 @@ __device__ __forceinline__ void dft_p(float2* v) {
     if constexpr (R > 10 || R == 7 || R == 9) dft_nat<R>(v);
 }
 
-// RCFM_FFT_ROWS_PITCH17 (default): rows-type tiles use a padded pitch of 17 points instead of the XOR
-// swizzle: constant LDS offsets instead of integer work per access; the transposing store stays
-// conflict-free (34-dword stride), 32-lane reads pay one extra LDS cycle.  Measured +1.4 % on cfg4
-// (the kernels are VALU-bound: SQ_ACTIVE_INST_VALU x waves per SIMD ~ 100 %, LDS far from busy).
-#ifndef RCFM_FFT_ROWS_PITCH17
-#define RCFM_FFT_ROWS_PITCH17 1
-#endif
-constexpr int kRowsPitch = RCFM_FFT_ROWS_PITCH17 ? W + 1 : W;
+// Rows-type tiles use a padded pitch of 17 points instead of the XOR swizzle: constant LDS offsets instead of integer
+// work per access; the transposing store stays conflict-free (34-dword stride), 32-lane reads pay one extra LDS cycle.
+// Measured +1.4 % on cfg4 (the kernels are VALU-bound: SQ_ACTIVE_INST_VALU x waves per SIMD ~ 100 %, LDS far from busy).
+constexpr int kRowsPitch = W + 1;
 
 // P17 = false (big tiles: the whole 80 KiB budget of a workgroup is tile) keeps the XOR swizzle for rows-type
 // tiles: same conflict-free accesses, a few integer instructions per access instead of 1/16 more LDS.
 template <bool SWZ, bool P17 = true>
 __device__ __forceinline__ int lds_slot(int row, int w) {
-    if (SWZ && RCFM_FFT_ROWS_PITCH17 && P17) return row * (W + 1) + w;
+    if (SWZ && P17) return row * (W + 1) + w;
     return SWZ ? row * W + (w ^ (row & (W - 1))) : row * W + w;
 }
 
@@ -640,23 +584,14 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
     }
 }
 
-// RCFM_FFT_BIG2 (default): the big tiles (600 / 625 / 640 points, 75 .. 80 KiB) run as TWO 1024-thread workgroups
-// per CU (32 waves, <= 64 VGPRs): while one workgroup waits for its tile the other one transforms.
-#ifndef RCFM_FFT_BIG2
-#define RCFM_FFT_BIG2 1
-#endif
-// RCFM_FFT_PAIR2_MIN: shortest tile that runs this way (experiments: 480 moves the 480/500-point tiles over too).
-#ifndef RCFM_FFT_PAIR2_MIN
-#define RCFM_FFT_PAIR2_MIN (kFftMaxL + 1)
-#endif
-constexpr bool big_tile_pair(int L) { return RCFM_FFT_BIG2 && L >= RCFM_FFT_PAIR2_MIN; }
-// RCFM_FFT_TRIPLE400 (default): the 400-point tile without its twiddle table in LDS is 51 200 B, so THREE 512-thread
-// workgroups fit a CU (<= 80 VGPRs; the rows form spills six dwords).  With the table (54 400 B, 57 600 with the
-// 17-point pitch) only two do.  Measured: cfg5 (400 . 625 . 400 wideband plan) 2.095 -> 2.067 ms, same-box alternation.
-#ifndef RCFM_FFT_TRIPLE400
-#define RCFM_FFT_TRIPLE400 1
-#endif
-constexpr bool triple_tile(int L) { return RCFM_FFT_TRIPLE400 && L == 400; }
+// The big tiles (600 / 625 / 640 points, 75 .. 80 KiB) run as TWO 1024-thread workgroups per CU (32 waves, <= 64 VGPRs):
+// while one workgroup waits for its tile the other one transforms.  (Moving the 480/500-point tiles over too measured
+// no change: those already have two workgroups per CU.)
+constexpr bool big_tile_pair(int L) { return L > kFftMaxL; }
+// The 400-point tile without its twiddle table in LDS is 51 200 B, so THREE 512-thread workgroups fit a CU (<= 80 VGPRs;
+// the rows form spills six dwords).  With the table (54 400 B, 57 600 with the 17-point pitch) only two do.  Measured:
+// cfg5 (400 . 625 . 400 wideband plan) 2.095 -> 2.067 ms, same-box alternation.
+constexpr bool triple_tile(int L) { return L == 400; }
 
 // LoadOp contract:  fetch(id, l, tile_base, off) returns element tile_base + off of the input
 //                   (tile_base is workgroup-uniform, off a 32-bit per-lane offset) and does NO
@@ -1469,32 +1404,21 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_de
 // ---- plain functors ------------------------------------------------------------
 // SWAP = exchange re/im: the inverse transform by the swap identity ifft(x) = swap(fft(swap(x))).
 
-// RCFM_FFT_NT: 1 = non-temporal loads, 2 = non-temporal stores, 3 = both.  Measured on MI355X
-// (c2c 256 x 240000 / N = 2.4e8): stores +3 % / +2 %, loads -7 % / -2 %: stores only.
-#ifndef RCFM_FFT_NT
-#define RCFM_FFT_NT (RCFM_TILE_W == 16 ? 2 : 0)   // (non-temporal stores are for whole 128-byte segments only: DESIGN.md section 8)
-#endif
-
-__device__ __forceinline__ float2 stream_load(const float2* p) {
-#if (RCFM_FFT_NT & 1)
-    using v2 = __attribute__((ext_vector_type(2))) float;
-    const v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
-    return make_float2(t.x, t.y);
-#else
-    return *p;
-#endif
-}
+// Streaming accesses of the tile passes, measured on MI355X (c2c 256 x 240000 / N = 2.4e8): non-temporal STORES +3 % /
+// +2 %, non-temporal loads -7 % / -2 %: loads are plain, stores non-temporal -- for whole 128-byte segments only (the
+// 16-line build; the 8-line build's 64-byte segments take plain stores: non-temporal partial lines stream at 2.4-3.6 TB/s).
+__device__ __forceinline__ float2 stream_load(const float2* p) { return *p; }
 
 __device__ __forceinline__ void stream_store(float2* p, float2 v) {
-#if (RCFM_FFT_NT & 2)
-    using v2 = __attribute__((ext_vector_type(2))) float;
-    v2 t;
-    t.x = v.x;
-    t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<v2*>(p));
-#else
-    *p = v;
-#endif
+    if constexpr (W == 16) {
+        using v2 = __attribute__((ext_vector_type(2))) float;
+        v2 t;
+        t.x = v.x;
+        t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<v2*>(p));
+    } else {
+        *p = v;
+    }
 }
 
 template <bool SWAP>
@@ -1551,20 +1475,12 @@ namespace fftk {
 
 // Lengths with a compile-time specialisation (radices listed first stage first; they must
 // match choose_radices() in fft_engine.hip).  Other lengths run the generic kernel.
-// RCFM_FFT_TWO_STAGE: the 480..640-point tiles as two LDS stages of composite radices (dft_nat).
-#ifndef RCFM_FFT_TWO_STAGE
-#define RCFM_FFT_TWO_STAGE 1
-#endif
+// The 480- and 500-point tiles run two LDS stages of composite radices (dft_nat); the pair kernel keeps three.
 #define RCFM_FFT_LONG_TABLE3(X) X(480, 10, 8, 6, 1) X(500, 10, 10, 5, 1)
-#if RCFM_FFT_TWO_STAGE && !defined(RCFM_FFT_LONG3)
 #define RCFM_FFT_LONG_TABLE(X) X(480, 24, 20, 1, 1) X(500, 25, 20, 1, 1)
-#else
-#define RCFM_FFT_LONG_TABLE(X) RCFM_FFT_LONG_TABLE3(X)
-#endif
 // Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.  Two stages of radix 24..32 leave
 // 60 % of the 1024 threads idle and measured slower here (3.1 vs 2.75 ms at N = 2.4e8).
 #define RCFM_FFT_BIG_LENGTHS(X) X(600, 10, 10, 6, 1) X(625, 5, 5, 5, 5) X(640, 10, 8, 8, 1)
-#if RCFM_FFT_TWO_STAGE
 // Two stages wherever both keep at least ~60 % of the threads on a butterfly (L / R >= 10 rows of 16 lanes
 // for 256 threads, >= 19 for 512); 125 as 25 x 5 (5 rows) measured 4 % slower on cfg5.
 #define RCFM_FFT_LENGTHS_(X, LONGT) \
@@ -1588,46 +1504,16 @@ namespace fftk {
     X(400, 20, 20, 1, 1)         \
     LONGT(X)                     \
     X(512, 8, 8, 8, 1)
-#else
-#define RCFM_FFT_LENGTHS_(X, LONGT) \
-    X(75, 5, 5, 3, 1)            \
-    X(80, 10, 8, 1, 1)           \
-    X(100, 10, 10, 1, 1)         \
-    X(120, 10, 6, 2, 1)          \
-    X(125, 5, 5, 5, 1)           \
-    X(128, 8, 8, 2, 1)           \
-    X(150, 10, 5, 3, 1)          \
-    X(160, 10, 8, 2, 1)          \
-    X(192, 8, 8, 3, 1)           \
-    X(200, 10, 10, 2, 1)         \
-    X(240, 10, 8, 3, 1)          \
-    X(250, 10, 5, 5, 1)          \
-    X(256, 8, 8, 4, 1)           \
-    X(300, 10, 6, 5, 1)          \
-    X(320, 10, 8, 4, 1)          \
-    X(375, 5, 5, 5, 3)           \
-    X(384, 8, 8, 6, 1)           \
-    X(400, 10, 10, 4, 1)         \
-    LONGT(X)                     \
-    X(512, 8, 8, 8, 1)
-#endif
 #define RCFM_FFT_FAST_LENGTHS(X) RCFM_FFT_LENGTHS_(X, RCFM_FFT_LONG_TABLE)
 // k_fft_tile2_pair keeps RL points per last-stage butterfly row in registers next to the point-wise
 // stage's inputs: with a last radix of 20 it spills, so it stays on three stages.
 #define RCFM_FFT_PAIR_LENGTHS(X) RCFM_FFT_LENGTHS_(X, RCFM_FFT_LONG_TABLE3)
 
 
-// Threads per tile.  Long tiles are LDS-limited to two workgroups per CU; 512 threads keep
-// 16 waves per CU in flight there (build with -DRCFM_FFT_LONG_THREADS=256 to compare).
-#ifndef RCFM_FFT_LONG_THREADS
-#define RCFM_FFT_LONG_THREADS 512
-#endif
-#ifndef RCFM_FFT_600_THREADS
-#define RCFM_FFT_600_THREADS 1024
-#endif
+// Threads per tile.  Long tiles are LDS-limited to two workgroups per CU; 512 threads keep 16 waves per CU in flight
+// there; the big tiles take 1024.
 constexpr int tile_threads(int L) {   // (RG = T / W butterfly rows per sweep is the same for every tile width)
-    return (L == 600 ? RCFM_FFT_600_THREADS : (L > kFftMaxL || big_tile_pair(L)) ? 1024 : L >= 320 ? RCFM_FFT_LONG_THREADS : 256) *
-           W / 16;
+    return (big_tile_pair(L) ? 1024 : L >= 320 ? 512 : 256) * W / 16;
 }
 
 // Big tiles are instantiated for the plain functors only (the streaming passes of long transforms).
@@ -1705,13 +1591,8 @@ inline bool fft_tile2_applies(const FftPassDev& d1, const FftPassDev& d2, int ba
 
 // Spectral decimation between two transforms (k_fft_tile2_decim): (long last-pass length, short
 // first-pass length) pairs with an instantiation.
-#if RCFM_FFT_TWO_STAGE
 #define RCFM_FFT_DECIM_500(X) X(500, 25, 20, 1, 1, 100, 10, 10)
 #define RCFM_FFT_DECIM_125(X) X(125, 5, 5, 5, 1, 80, 10, 8)
-#else
-#define RCFM_FFT_DECIM_500(X) X(500, 10, 10, 5, 1, 100, 10, 10)
-#define RCFM_FFT_DECIM_125(X) X(125, 5, 5, 5, 1, 80, 10, 8)
-#endif
 #define RCFM_FFT_DECIM_PAIRS(X)          \
     RCFM_FFT_DECIM_500(X)                \
     RCFM_FFT_DECIM_125(X)

@@ -37,21 +37,7 @@ using fftk::dft_slot;
 using fftk::lds_barrier;
 using fftk::twiddle_powers;
 
-// -DRCFM_LDS_CHAIN_TRACE (timing experiments): workgroup 0 records s_memtime at every phase boundary and the launcher
-// prints the differences after a synchronisation.
-#ifdef RCFM_LDS_CHAIN_TRACE
-#define RCFM_TRACE_POINT(i) \
-    do { if (blockIdx.x == 0 && threadIdx.x == 0) p.trace[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define RCFM_TRACE_POINT(i) do { } while (0)
-#endif
-
-#ifndef RCFM_LDS_CHAIN_FUSED_GATHER
-#define RCFM_LDS_CHAIN_FUSED_GATHER 1
-#endif
-
 struct ChainDev {
-    long long* trace;             // RCFM_LDS_CHAIN_TRACE builds only
     LdsChainArgs a;
     float two_pi_over_n, delta;   // window argument of source offset d: d * 2 pi / N + delta
     float c0, c1, c2, c3;         // a0 + (1 - a0) cos(th) as a series in th^2 (|th| < 0.25: fused_passes.hip)
@@ -126,13 +112,13 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     // The B bins of one channel, raw, into registers: issued one phase AHEAD of their use (the member's loads fly
     // under the previous member's arctangents, the next pair's under this pair's IFFT_A) -- with one workgroup per CU
     // nothing else would hide the memory latency.
-    // RCFM_LDS_CHAIN_FUSED_GATHER (default): the bins arrive in the order the first stage of IFFT_B consumes them --
+    // Fused gather: the bins arrive in the order the first stage of IFFT_B consumes them --
     // thread b holds points b + q (B / R0), q < R0, of one radix-R0 butterfly -- so window, Nyquist merge and that stage
     // run straight from the prefetched registers and xs is written once, already transformed: one LDS write + barrier +
     // LDS read less per member than "gather to xs, then stage 1" (round 3).  The loads stay coalesced (lanes = adjacent b).
     // (The 640-thread instantiations are capped at 168 VGPRs and spill another 200 dwords in this form: they keep round 3's.)
     constexpr int M0 = B / R0;                                   // butterflies of the first stage
-    constexpr bool kFused = RCFM_LDS_CHAIN_FUSED_GATHER && T <= 512 && M0 <= T;
+    constexpr bool kFused = T <= 512 && M0 <= T;
     constexpr int NV = kFused ? R0 : NL;
     float2 v[NV], x2;
     auto issue_gather = [&](int c) {
@@ -164,7 +150,6 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     // ---- the two channels: gather -> IFFT_B -> phases --------------------------------------------------------
     auto member = [&](auto MEM) {                               // (straight-line for both members: no conditional
         constexpr int mem = decltype(MEM)::value;               //  definition keeps the prefetched bins alive longer)
-        RCFM_TRACE_POINT(mem * 6 + 0);
         float2 m2 = make_float2(0.f, 0.f);
         if (p.a.merge >= 0) {
             const float w2 = window(-p.a.merge);
@@ -172,7 +157,6 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         }
         // (xs is free: member 0 starts behind the previous pair's closing barrier, member 1 behind the one below)
         if constexpr (kFused) {
-            RCFM_TRACE_POINT(mem * 6 + 1);
             if (tid < M0) {
                 const float2 w1 = p.twB[tid];                   // W_B^b: the first stage's twiddle of butterfly b
                 float2 u[R0];
@@ -203,19 +187,15 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
                 }
             }
             lds_barrier();
-            RCFM_TRACE_POINT(mem * 6 + 1);
             chain_stage<B, R0, B, T>(xs, p.twB, tid);
             lds_barrier();
         }
-        RCFM_TRACE_POINT(mem * 6 + 2);
         chain_stage<B, R1, B / R0, T>(xs, p.twB, tid);
         lds_barrier();
-        RCFM_TRACE_POINT(mem * 6 + 3);
         float2 y[R2];
         const int kb = chain_last<B, R0, R1, R2, T>(xs, tid, y);
         if constexpr (mem == 0) issue_gather(c1);               // member 1's bins fly under member 0's arctangents
         lds_barrier();                                          // every read of xs is done (th1 overlays it; member 1 refills it)
-        RCFM_TRACE_POINT(mem * 6 + 4);
         if (tid < B / R2) {
             float* dst = mem ? th1 : ds;
 #pragma unroll
@@ -224,12 +204,10 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
                 dst[kb + (B / R2) * q] = atan2_over_pi(z.x, z.y);
             }
         }
-        RCFM_TRACE_POINT(mem * 6 + 5);
     };
     member(std::integral_constant<int, 0>{});
     member(std::integral_constant<int, 1>{});
     lds_barrier();
-    RCFM_TRACE_POINT(12);
 
     // ---- u[t] = d0[t] + j d1[t]: the wrapped phase steps of both channels (fm.py:60-65) ---------------------------
     // two adjacent samples per thread: theta[t0 - 1] and the aligned pair (theta[t0], theta[t0 + 1]) of each member,
@@ -278,15 +256,12 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         }
     }
     lds_barrier();
-    RCFM_TRACE_POINT(13);
 
     // ---- FFT_B(u), decimation to A (decimate.py:48 for the packed pair: the weight is real and even) ---------------
     chain_stage<B, R0, B, T>(xs, p.twB, tid);
     lds_barrier();
-    RCFM_TRACE_POINT(14);
     chain_stage<B, R1, B / R0, T>(xs, p.twB, tid);
     lds_barrier();
-    RCFM_TRACE_POINT(15);
     {
         float2 y[R2];
         const int kb = chain_last<B, R0, R1, R2, T>(xs, tid, y);
@@ -324,7 +299,6 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         }
     }
     lds_barrier();
-    RCFM_TRACE_POINT(16);
     if (tid == 0) {
         const float2 a = xs[A / 2], b = xs[A];
         xs[A / 2] = make_float2(a.x + b.x, a.y + b.y);
@@ -335,13 +309,10 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
     lds_barrier();
 
     // ---- IFFT_A: real part -> member 0, imaginary part -> member 1 -----------------------------------------------
-    RCFM_TRACE_POINT(17);
     chain_stage<A, Q0, A, T>(xs, p.twA, tid);
     lds_barrier();
-    RCFM_TRACE_POINT(18);
     chain_stage<A, Q1, A / Q0, T>(xs, p.twA, tid);
     lds_barrier();
-    RCFM_TRACE_POINT(19);
     {
         float2 y[Q2];
         const int kb = chain_last<A, Q0, Q1, Q2, T>(xs, tid, y);
@@ -352,7 +323,6 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
         }
     }
     lds_barrier();
-    RCFM_TRACE_POINT(20);
     float* out0 = p.a.audio + (int64_t)c0 * A;
     float* out1 = p.a.audio + (int64_t)c1 * A;
     if constexpr (DEEMPH) {
@@ -475,15 +445,12 @@ __global__ __launch_bounds__(T) void k_fm_lds(ChainDev p) {
             if (has1) out1[i] = s0.x;
         }
     }
-    RCFM_TRACE_POINT(21);
     lds_barrier();                                              // the next pair refills xs
     }   // pairs of this workgroup
 }
 
 // (B; R0, R1, R2 | A; Q0, Q1, Q2 | threads): each stage has at most `threads` butterflies.
-#ifndef RCFM_LDS_CHAIN_T
 #define RCFM_LDS_CHAIN_T 512   // 640 threads (one sweep in every stage) spill 87 dwords at 168 VGPRs: 1.13 vs 0.81 ms on cfg5
-#endif
 #define RCFM_LDS_CHAINS(X)                          \
     X(12500, 25, 20, 25, 8000, 20, 20, 20, RCFM_LDS_CHAIN_T)     \
     X(12500, 25, 20, 25, 6250, 25, 10, 25, 640)     \
@@ -514,23 +481,6 @@ const float2* twiddle_table(int n) {
     return it->second->as<float2>();
 }
 
-void trace_report(const ChainDev& p, hipStream_t stream) {
-#ifdef RCFM_LDS_CHAIN_TRACE
-    static const char* const names[21] = {
-        "m0 gather", "m0 stage 1", "m0 stage 2", "m0 last", "m0 atan2", "(loop)", "m1 gather", "m1 stage 1", "m1 stage 2",
-        "m1 last", "m1 atan2", "(barrier)", "phase steps", "F stage 1", "F stage 2", "F last+decim", "nyquist",
-        "A stage 1", "A stage 2", "A last+reorder", "store"};
-    long long t[22];
-    RC_HIP(hipStreamSynchronize(stream));
-    RC_HIP(hipMemcpy(t, p.trace, sizeof(t), hipMemcpyDeviceToHost));
-    fprintf(stderr, "lds_chain trace (s_memtime ticks, workgroup 0): total %lld\n", t[21] - t[0]);
-    for (int i = 0; i < 21; ++i) fprintf(stderr, "  %-16s %7lld\n", names[i], t[i + 1] - t[i]);
-#else
-    (void)p;
-    (void)stream;
-#endif
-}
-
 }  // namespace
 
 bool lds_chain_supported(int B, int A) {
@@ -555,11 +505,6 @@ bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream
     if (args.count <= 0) return true;
     if (!lds_chain_supported(B, A)) return false;
     ChainDev p;
-    p.trace = nullptr;
-#ifdef RCFM_LDS_CHAIN_TRACE
-    static DeviceBuffer trace_buf(32 * sizeof(long long));
-    p.trace = trace_buf.as<long long>();
-#endif
     p.a = args;
     const double a0 = 0.5, a1 = 1.0 - a0;                      // fftshifted periodic Hann (tuner.py:156-157)
     p.two_pi_over_n = (float)(6.28318530717958647692 / (double)args.N);
@@ -586,7 +531,6 @@ bool launch_lds_chain(int B, int A, const LdsChainArgs& args, hipStream_t stream
         if (!deemph)                                                                                               \
             hipLaunchKernelGGL((k_fm_lds<B_, R0, R1, R2, A_, Q0, Q1, Q2, T_, false>), grid, dim3(T_), 0, stream, p); \
         RC_HIP(hipGetLastError());                                                                                 \
-        trace_report(p, stream);                                                                                   \
         return true;                                                                                               \
     }
     RCFM_LDS_CHAINS(RCFM_CASE)

@@ -129,8 +129,8 @@ def test_run_all_narrowband_fm_geometry(rc, oracle, kind, B, A, chunk):
 
 
 def test_lds_chain_pairing_does_not_matter(rc, oracle):
-    """The same narrow band through the LDS-resident kernel and (RCFM_LDS_CHAIN=0 is read once per process, so
-    through a sharded call that starts at an odd channel index instead) a different pairing: a channel's audio must
+    """The same narrow band through the LDS-resident kernel and, through a sharded call that starts at an odd channel
+    index, a different pairing: a channel's audio must
     not depend on which neighbour shares its complex transform beyond float32 rounding."""
     N, B, A, C = 1_000_000, 12500, 8000, 20
     centres = workloads.channel_grid(C, 12000)
