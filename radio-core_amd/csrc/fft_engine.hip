@@ -375,7 +375,8 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
             else if (keep != nullptr)
                 launch_fft_pass<kRowsOnly>(dev, batch, ld,
                                            StoreRowWindow{out, scale, (int)dev.p.n_o1, (int)dev.p.n_o2, keep->lo, keep->hi,
-                                                          n, batch == 1 ? keep->halo : 0},
+                                                          n, batch == 1 ? keep->halo : 0,
+                                                          (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20)},
                                            stream);
             else
                 launch_fft_pass<kRowsOnly>(dev, batch, ld, StorePlainT<false>{out, scale}, stream);

@@ -1452,13 +1452,22 @@ struct StoreRowWindow {
     // front of the start (out[n + g] and out[g - n]): the tuner's haloed spectrum without two extra copy launches.
     int64_t n = 0;
     int halo = 0;
+    int sc1_straddle = 0;   // 1: segments that straddle two 128-byte lines leave with sc1 (outputs beyond the Infinity Cache)
     __device__ __forceinline__ void operator()(const LineId& id, int k, int64_t base, unsigned off, float2 v) const {
         const int row = (int)id.o1 + n_o1 * ((int)id.o2 + n_o2 * k);
         const bool keep = lo <= hi ? (row >= lo && row <= hi) : (row >= lo || row <= hi);
         if (!keep) return;
         const float2 y = make_float2(v.x * scale, v.y * scale);
         const int64_t g = base + off;
-        stream_store(out + g, y);
+        // Half of this pass's 128-byte segments straddle two lines when the output stride is an odd multiple of 64 bytes
+        // (N = 2.4e8: 375 000 bins): those leave with sc1, the aligned ones non-temporal.  Same-address A/B: wideband FFT
+        // 2.245 -> 2.221 ms (plain stores for the straddling ones: 2.285; sc1 or plain for ALL of them: slower than nt;
+        // profiles/r05_b_kernel_ab.txt, r05_s_row_store_mix.txt).
+        // Only for outputs that stream to HBM: a cache-resident transform (N = 1e7) measured 0.8 % slower with it.
+        const bool straddle = sc1_straddle &&
+                              ((reinterpret_cast<uintptr_t>(out + g) - ((uintptr_t)((int)id.i & (W - 1)) << 3)) & 127u) != 0;
+        if (straddle) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(out + g), "v"(y) : "memory");
+        else stream_store(out + g, y);
         if (halo > 0) {
             if (g < halo) out[n + g] = y;
             else if (g >= n - halo) out[g - n] = y;
