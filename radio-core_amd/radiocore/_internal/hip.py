@@ -11,6 +11,7 @@ torch.cuda.current_stream); no torch operator computes any part of the path.
 import ctypes
 import os
 import sys
+import threading
 import warnings
 
 import numpy as np
@@ -252,12 +253,20 @@ class Handle:
 
 # ---- placement (rcfm_arena_*) ----------------------------------------------------------------------------------------
 
-_arena_stack = []
+_arena_tls = threading.local()      # like librcfm's own binding (rcfm_arena_bind), the open `with Arena` is per thread
+
+
+def _arena_stack():
+    st = getattr(_arena_tls, "stack", None)
+    if st is None:
+        st = _arena_tls.stack = []
+    return st
 
 
 def current_arena():
-    """The Arena whose `with` block is open on this thread of control (None: hipMalloc per workspace)."""
-    return _arena_stack[-1] if _arena_stack else None
+    """The Arena whose `with` block is open on THIS thread (None: hipMalloc per workspace)."""
+    st = _arena_stack()
+    return st[-1] if st else None
 
 
 class Arena:
@@ -285,11 +294,11 @@ class Arena:
         return self._handle.value
 
     def __enter__(self):
-        _arena_stack.append(self)
+        _arena_stack().append(self)
         return self
 
     def __exit__(self, *exc):
-        _arena_stack.pop()
+        _arena_stack().pop()
         return False
 
     def stats(self):
