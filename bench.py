@@ -468,7 +468,7 @@ def measure_cfg2_single(reps=200):
 
 # rcfm_demod_set_option names (include/rcfm.h)
 DEMOD_OPTIONS = {"lds_chain": 1, "fused_tiles": 2, "phase_link": 3, "narrow_tiles": 4, "pilot_chain": 6, "decim_tile": 7,
-                 "lds_deemph": 8}
+                 "lds_deemph": 8, "pilot_blocked": 9}
 
 
 def apply_options(lib, hip, demod, opts):

@@ -199,6 +199,8 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *                         the two switches below together
  *   RCFM_OPT_PILOT_CHAIN  ... only the tiles around the Hilbert mask (pilot pair FFT -> mask -> IFFT -> stereo matrix)
  *   RCFM_OPT_DECIM_TILE   ... only the spectral decimation between FFT_B's last pass and IFFT_A's first
+ *   RCFM_OPT_PILOT_BLOCKED WBFM's mono signal and pilot band travel from the pilot stage to the pilot chain in a tile-blocked
+ *                         layout (the chain's 16-line tiles read contiguous runs; 0: natural order, half-line reads)
  *   RCFM_OPT_LDS_DEEMPH   narrow MFM channels: de-emphasis, mean removal and clip inside the LDS chain (0: the
  *                         de-emphasis launches behind it)
  *   RCFM_OPT_PHASE_LINK   the tuner hands the demodulator angle(x) / pi as float32 (0: complex64 samples, as
@@ -216,7 +218,7 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *                         shared state waits for the event the previous one recorded, on whichever stream that was.
  *                         Set it on any ONE handle of the sharing group, after the binding */
 enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5,
-       RCFM_OPT_PILOT_CHAIN = 6, RCFM_OPT_DECIM_TILE = 7, RCFM_OPT_LDS_DEEMPH = 8 };
+       RCFM_OPT_PILOT_CHAIN = 6, RCFM_OPT_DECIM_TILE = 7, RCFM_OPT_LDS_DEEMPH = 8, RCFM_OPT_PILOT_BLOCKED = 9 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 

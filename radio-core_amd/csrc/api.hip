@@ -589,6 +589,7 @@ struct rcfm_demod_s {
     bool opt_lds_chain = true;
     bool opt_pilot_chain = true;     // pilot chain, Hilbert pair / packed tiles (two transforms per tile around the mask)
     bool opt_decim_tile = true;      // spectral decimation between FFT_B's last pass and IFFT_A's first
+    bool opt_pilot_blocked = true;   // m, p between the pilot stage and the pilot chain in the tile-blocked layout
     bool opt_phase_link = true;
     bool opt_lds_deemph = true;      // MFM's de-emphasis inside the LDS chain
     int opt_narrow = kNarrowDefault;   // RCFM_OPT_NARROW_TILES
@@ -601,8 +602,6 @@ struct rcfm_demod_s {
         tiles = fir_tiles(A);
 
         if (kind == RCFM_WBFM) {
-            buf_m.reset(c * B * sizeof(float));
-            buf_p.reset(c * B * sizeof(float));
             buf_P.reset(c * (B / 2 + 1) * sizeof(float2));
             buf_Z.reset(c * B * sizeof(float2));      // analytic pilot, then the packed L/R signal
             buf_V.reset(c * A * sizeof(float2));      // packed audio spectrum -> l + j r
@@ -668,6 +667,13 @@ struct rcfm_demod_s {
                 buf_Z.reset(c * B * sizeof(float2));   // full spectrum of the discriminator output
                 buf_V.reset(c * A * sizeof(float2));   // Hermitian audio spectrum
             }
+        }
+        if (kind == RCFM_WBFM) {
+            // mono signal and pilot band (after the engines: the tile-blocked layout of the pilot chain pads the last
+            // 16-column block of every row, PilotBlocked::stride >= B)
+            const size_t per_channel = std::max<size_t>((size_t)B, (size_t)pilot_blocked().stride);
+            buf_m.reset(c * per_channel * sizeof(float));
+            buf_p.reset(c * per_channel * sizeof(float));
         }
     }
 
@@ -749,6 +755,14 @@ struct rcfm_demod_s {
         }
     }
 
+    // The tile-blocked layout of m and p (kernels.h) when the pilot chain's geometry allows it, else an invalid one.
+    PilotBlocked pilot_blocked() const {
+        int64_t rows = 0, row_length = 0;
+        if (kind != RCFM_WBFM || !eng_B || !eng_Bi || B % 4 != 0 || !fused_pilot_chain_geometry(*eng_B, &rows, &row_length))
+            return PilotBlocked{};
+        return PilotBlocked::plan(rows, row_length);
+    }
+
     // Does run_chunk take the samples' phases (theta = angle(x) / pi, float32 [cnt][B]) instead of iq?
     bool phase_capable() const { return eng_B != nullptr && (kind != RCFM_WBFM || B % 4 == 0); }
 
@@ -770,13 +784,16 @@ struct rcfm_demod_s {
             float2* P = buf_P.as<float2>();
             float2* Z = buf_Z.as<float2>();
             float2* V = buf_V.as<float2>();
+            // the three-launch pilot chain reads m and p as 16-line tiles: they leave the pilot stage tile-blocked then
+            const bool chain = eng_B && eng_Bi && opt_pilot_chain && TILE_CALL(nw, fused_pilot_chain_applies, *eng_B, *eng_Bi, cnt);
+            const PilotBlocked blk = (chain && opt_pilot_blocked) ? pilot_blocked() : PilotBlocked{};
             // wbfm.py:77-80  FM(B->B) and the pilot band-pass
             {
                 StageTimer tm(ST_PILOT, s);
                 if (theta != nullptr)
-                    launch_pilot_stage_h40_phase(theta, m, p, B, cnt, pilot_g_h, side_tap, s);
+                    launch_pilot_stage_h40_phase(theta, m, p, B, cnt, pilot_g_h, side_tap, s, &blk);
                 else if (B % 4 == 0)
-                    launch_pilot_stage_h40(iq, m, p, B, cnt, pilot_g_h, side_tap, s);
+                    launch_pilot_stage_h40(iq, m, p, B, cnt, pilot_g_h, side_tap, s, &blk);
                 else
                     launch_pilot_stage(iq, nullptr, m, p, B, cnt, pilot_g.as<float>(), 40, side_tap, s);
             }
@@ -785,17 +802,17 @@ struct rcfm_demod_s {
                 float2* TA = buf_TA.as<float2>();
                 float2* U2 = buf_U2.as<float2>();
                 // RCFM_OPT_PILOT_CHAIN = 0: pair FFT -> U2 -> masked IFFT as separate transforms
-                const bool chain = eng_Bi && opt_pilot_chain && TILE_CALL(nw, fused_pilot_chain_applies, *eng_B, *eng_Bi, cnt);
                 const bool packed = eng_Bi && opt_pilot_chain && TILE_CALL(nw, fused_hilbert_packed_applies, *eng_Bi, *eng_B, cnt);
                 bool paired = false;
                 if (chain) {
                     {   // wbfm.py:80 / pll.py:34: spectra of the pilot bands, two channels per complex FFT
                         StageTimer tm(ST_FFT_REAL_B, s);
-                        TILE_CALL(nw, fused_pilot_chain_fft_first, *eng_B, p, T, cnt, s);
+                        TILE_CALL(nw, fused_pilot_chain_fft_first, *eng_B, p, T, cnt, s, blk.stride, blk.blk16());
                     }
                     {   // ... last pass, one-sided mask, inverse FFT, stereo matrix, first pass of the packed L/R FFT
                         StageTimer tm(ST_IFFT_B, s);
-                        TILE_CALL(nw, fused_pilot_chain_mask_mix, *eng_B, *eng_Bi, p, m, T, buf_Ti.as<float2>(), cnt, s);
+                        TILE_CALL(nw, fused_pilot_chain_mask_mix, *eng_B, *eng_Bi, p, m, T, buf_Ti.as<float2>(), cnt, s, blk.stride,
+                                  blk.blk16());
                     }
                     paired = true;
                 } else {
@@ -1531,6 +1548,7 @@ int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
             case RCFM_OPT_FUSED_TILES: d->opt_pilot_chain = d->opt_decim_tile = value != 0; break;
             case RCFM_OPT_PILOT_CHAIN: d->opt_pilot_chain = value != 0; break;
             case RCFM_OPT_DECIM_TILE: d->opt_decim_tile = value != 0; break;
+            case RCFM_OPT_PILOT_BLOCKED: d->opt_pilot_blocked = value != 0; break;
             case RCFM_OPT_LDS_DEEMPH: d->opt_lds_deemph = value != 0; break;
             case RCFM_OPT_PHASE_LINK: d->opt_phase_link = value != 0; break;
             case RCFM_OPT_NARROW_TILES:

@@ -1053,11 +1053,14 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2_pa
     const int left = (int)p1.n_inner - i0;
     const int wvalid = left < W ? left : W;
     const int64_t in_base = (int64_t)id.batch * d1.in_batch + (int64_t)i0 * p1.in_i;
-    const int64_t mid_base0 = (int64_t)c0 * d1.out_batch + i0;      // natural-order signals of the members
-    const int64_t mid_base1 = (int64_t)c1 * d1.out_batch + i0;
+    // natural-order signals of the members -- or tile-blocked ones (MidOp::blk16: the tile's 16 L values contiguous)
+    const int blk16 = mid.blk16;
+    const int64_t mid_tile = blk16 ? (int64_t)(i0 >> 4) * blk16 + (i0 & 15) : (int64_t)i0;
+    const int64_t mid_base0 = (int64_t)c0 * (blk16 ? mid.stride : d1.out_batch) + mid_tile;
+    const int64_t mid_base1 = (int64_t)c1 * (blk16 ? mid.stride : d1.out_batch) + mid_tile;
     const int64_t out_base0 = (int64_t)c0 * d2.out_batch + i0;
     const int64_t out_base1 = (int64_t)c1 * d2.out_batch + i0;
-    const unsigned in_i = (unsigned)p1.in_i, mid_k = (unsigned)p1.out_k, out_k = (unsigned)p2.out_k;
+    const unsigned in_i = (unsigned)p1.in_i, mid_k = blk16 ? 16u : (unsigned)p1.out_k, out_k = (unsigned)p2.out_k;
     const int wc = w < wvalid ? w : 0;
 
     auto kbase = [](int g) -> int {

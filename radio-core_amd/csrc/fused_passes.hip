@@ -142,9 +142,18 @@ struct LoadRealAsComplex {
 struct LoadRealPair {
     const float* x;
     int n, count;
-    __device__ __forceinline__ float2 fetch(const LineId& id, int, int64_t base, unsigned off) const {
-        // in_batch = 0: base + off = sample index inside the signal
+    // blk16 != 0: x is tile-blocked (PilotBlocked, kernels.h): channel stride `stride`, line i of row l at
+    // (i / 16) blk16 + 16 l + i % 16 -- the 16 (8) lines of a tile read one contiguous run
+    int64_t stride = 0;
+    int blk16 = 0;
+    __device__ __forceinline__ float2 fetch(const LineId& id, int l, int64_t base, unsigned off) const {
+        // in_batch = 0: base + off = sample index inside the signal, base = the tile's first line
         const int c0 = 2 * id.batch, c1 = (c0 + 1 < count) ? c0 + 1 : c0;
+        if (blk16) {
+            const int i = (int)id.i;
+            const int64_t a = (int64_t)(i >> 4) * blk16 + l * 16 + (i & 15);
+            return make_float2(x[(int64_t)c0 * stride + a], x[(int64_t)c1 * stride + a]);
+        }
         const int64_t a = base + off;
         return make_float2(x[(int64_t)c0 * n + a], x[(int64_t)c1 * n + a]);
     }
@@ -354,6 +363,10 @@ struct MidHilbertMaskT {
 struct MidStereoMixPair {
     const float* p;   // [count][n] pilot bands
     const float* m;   // [count][n] mono signals
+    // blk16 != 0: both are tile-blocked (PilotBlocked, kernels.h) with `stride` floats per channel; the kernel then
+    // takes its row pitch (16) and tile base from here instead of the plan
+    int64_t stride = 0;
+    int blk16 = 0;
     struct In0 { float p0, p1, m0; };
     using Keep = float;   // member 1's carrier s2 = Im(z1^2)/|z1^2|
     // uniform 64-bit base + 32-bit lane byte offset: one VGPR of address per point, shared by the
@@ -683,16 +696,28 @@ bool fused_pilot_chain_applies(const FftEngine& ef, const FftEngine& ei, int cou
            fftk::fft_tile2_applies(ei.pass_dev(1, ei.tmp_stride(), n), ef.pass_dev(0, n, ef.tmp_stride()), pairs);
 }
 
-void fused_pilot_chain_fft_first(const FftEngine& ef, const float* p, float2* tmp_f, int count, hipStream_t s) {
+bool fused_pilot_chain_geometry(const FftEngine& ef, int64_t* rows, int64_t* row_length) {
+    if (ef.npass() != 2) return false;
+    const FftPass& p0 = ef.desc().pass[0];
+    if (p0.load_along_l || p0.in_i != 1 || p0.n_o1 != 1 || p0.n_o2 != 1 || (int64_t)p0.L * p0.in_l != ef.desc().n ||
+        p0.n_inner != p0.in_l)
+        return false;
+    *rows = p0.L;
+    *row_length = p0.in_l;
+    return true;
+}
+
+void fused_pilot_chain_fft_first(const FftEngine& ef, const float* p, float2* tmp_f, int count, hipStream_t s,
+                                 int64_t blk_stride, int blk16) {
     if (count <= 0) return;
     const int64_t n = ef.desc().n;
-    LoadRealPair ld{p, (int)n, count};
+    LoadRealPair ld{p, (int)n, count, blk_stride, blk16};
     fftk::StorePlainT<false> st0{tmp_f, 1.0f};
     fftk::launch_fft_pass<kStridedOnly>(ef.pass_dev(0, 0, ef.tmp_stride()), (count + 1) / 2, ld, st0, s);
 }
 
 void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const float* p, const float* m,
-                                float2* tmp_f, float2* tmp_i, int count, hipStream_t s) {
+                                float2* tmp_f, float2* tmp_i, int count, hipStream_t s, int64_t blk_stride, int blk16) {
     if (count <= 0) return;
     const int64_t n = ef.desc().n;
     const int pairs = (count + 1) / 2;
@@ -713,7 +738,9 @@ void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const 
         const FftPassDev d1 = ei.pass_dev(1, ei.tmp_stride(), n);
         const FftPassDev d2 = ef.pass_dev(0, n, ef.tmp_stride());
         fftk::LoadPlainT<false> ld{tmp_i};
-        MidStereoMixPair mid{p, m};
+        MidStereoMixPair mid{p, m, blk_stride, blk16};
+        RC_REQUIRE(!blk16 || (blk16 >= 16 * d1.p.L && (int64_t)d1.p.L * d1.p.out_k == n), RCFM_ERR_RUNTIME,
+                   "tile-blocked pilot layout does not match the inverse transform's last pass");
         fftk::StorePlainT<false> st{tmp_f, 1.0f};
         RC_REQUIRE(fftk::launch_fft_tile2_pair(d1, d2, count, ld, mid, st, s), RCFM_ERR_RUNTIME,
                    "two-transform pair kernel refused a pair it should accept");

@@ -58,10 +58,16 @@ bool fused_hilbert_packed_ifft_mix_fft(const FftEngine& ei, const FftEngine& ef,
 // tile (k_fft_tile2): the pair spectrum never reaches memory;  (3) the inverse FFT's last pass + split
 // into the two analytic signals + stereo mix + first pass of each member's packed L/R FFT
 // (k_fft_tile2_pair).  Leaves ef's scratch tmp_f ready for fused_fft_last_pruned.
+// blk16 != 0: p and m are in the tile-blocked layout of PilotBlocked (kernels.h) for the L x R view of the signal
+// that fused_pilot_chain_geometry reports (rows = points of the pair FFT's first pass, row_length = their distance):
+// both readers then fetch whole contiguous tiles instead of half lines (blk_stride floats per channel, blk16 = 16 L).
 bool fused_pilot_chain_applies(const FftEngine& ef, const FftEngine& ei, int count);
-void fused_pilot_chain_fft_first(const FftEngine& ef, const float* p, float2* tmp_f, int count, hipStream_t s);
+bool fused_pilot_chain_geometry(const FftEngine& ef, int64_t* rows, int64_t* row_length);
+void fused_pilot_chain_fft_first(const FftEngine& ef, const float* p, float2* tmp_f, int count, hipStream_t s,
+                                 int64_t blk_stride = 0, int blk16 = 0);
 void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const float* p, const float* m,
-                                float2* tmp_f, float2* tmp_i, int count, hipStream_t s);
+                                float2* tmp_f, float2* tmp_i, int count, hipStream_t s, int64_t blk_stride = 0,
+                                int blk16 = 0);
 
 void fused_fft_last_pruned(const FftEngine& ef, const float2* tmp_f, float2* out, int count, int keep,
                            hipStream_t s);

@@ -56,14 +56,33 @@ void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipS
 void launch_pilot_stage(const float2* iq, const float* x, float* m_out, float* p_out, int64_t n,
                         int batch, const float* g, int H, float side_tap, hipStream_t stream);
 
+// Tile-blocked layout of the real signals m and p for readers that walk them as 16-line tiles of an L x R
+// matrix (sample t = k R + i: the first pass of the pair FFT and the point-wise stage of k_fft_tile2_pair):
+// element (k, i) of channel c sits at  c stride + (i / 16) bs + 16 k + i % 16  (bs >= 16 L),  so the 16 L values of a tile
+// are one contiguous run instead of L 64-byte half lines R floats apart (each fetched as a whole line, half of
+// them twice).  valid() = the pilot stage can write it: whole row PAIRS per workgroup (rpt rows, even), so that
+// every 128-byte line (rows k, k + 1 of one 16-column block) leaves in one store instruction.
+struct PilotBlocked {
+    int R = 0, L = 0;       // row length (columns), rows: n = L R
+    int rpt = 0, nb = 0;    // rows per workgroup (even, rpt R <= 2048), 16-column blocks per row
+    int bs = 0;             // floats from one 16-column block to the next (>= 16 L)
+    unsigned half_magic = 0;   // ceil(2^32 / (rpt / 2)): the stage's one division as a multiply-high
+    int64_t stride = 0;     // floats per channel: nb * bs
+    bool valid() const { return rpt > 0; }
+    int blk16() const { return valid() ? bs : 0; }
+    // the layout for an n = L R signal, or an invalid one when the stage would waste more than an eighth of its
+    // threads (rpt R < 1792 of 2048), R is not a multiple of 4 (16-byte stores) or the signal is shorter than a workgroup
+    static PilotBlocked plan(int64_t L, int64_t R);
+};
+
 // The same chain specialised for WBFM's 41-tap pilot filter (H = 40); g_host: 41 taps on the host.
-// Needs n % 4 == 0 (16-byte stores) and n > 123.
+// Needs n % 4 == 0 (16-byte stores) and n > 123.  blk (optional, valid()): m and p leave tile-blocked.
 void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
-                            const float* g_host, float side_tap, hipStream_t stream);
+                            const float* g_host, float side_tap, hipStream_t stream, const PilotBlocked* blk = nullptr);
 // The same chain from the samples' phases theta = angle(x) / pi (what the pipeline's tuner stage leaves,
 // fused_tuner_ifft): d[i] = the phase step wrapped into [-1, 1], exactly diff(unwrap(angle(x))) / pi.
 void launch_pilot_stage_h40_phase(const float* theta, float* m_out, float* p_out, int64_t n, int batch,
-                                  const float* g_host, float side_tap, hipStream_t stream);
+                                  const float* g_host, float side_tap, hipStream_t stream, const PilotBlocked* blk = nullptr);
 void launch_discriminator_phase(const float* theta, float* d, int64_t n, int batch, hipStream_t stream);
 
 // wbfm.py:83,86-87: s2 = Im(z^2)/|z^2|; lmr = s2 m 1.0175; u = (m + lmr) + j (m - lmr).

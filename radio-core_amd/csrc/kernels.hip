@@ -271,7 +271,8 @@ struct PilotTaps {
 
 constexpr int kPilotPer = 8;
 constexpr int kPilotFastTile = kThreads * kPilotPer;   // 2048 outputs per workgroup
-
+constexpr int kPilotBlockedThreads = kThreads;         // tile-blocked output (PilotBlocked): whole rows per workgroup
+constexpr int kPilotBlockedTile = kPilotBlockedThreads * kPilotPer;
 // acc += taps (.) w and acc += reverse(taps) (.) w, taps in an SGPR pair: the halves are picked by
 // op_sel, so the symmetric kernel serves even and odd outputs from one set of aligned pairs.
 __device__ __forceinline__ void pk_fma_s(v2f& acc, v2f taps, v2f w) {
@@ -288,13 +289,18 @@ __device__ __forceinline__ float phase_step_fast(float2 a, float2 b) {
 __device__ __forceinline__ float phase_step_fast(float th, float th_prev) { return phase_step_wrapped(th, th_prev); }
 
 // IN = float2: complex samples; IN = float: their phases in units of pi.
-template <class IN>
-__global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restrict__ iq,
+// BLK: m and p leave in the tile-blocked layout of PilotBlocked (kernels.h); a workgroup then owns rpt whole rows
+// (Tv = rpt R <= T outputs; the threads beyond idle through the FIR) and tiles_x = ceil(L / rpt).  (THREADS = 1024,
+// 16 rows of 500 per workgroup and 1 KB runs per block, was slower still than 256 threads with their 256-byte runs:
+// 0.76 against 0.64 ms, 0.57 in natural order -- profiles/r05_z_pilot_blocked.md.)
+template <class IN, bool BLK, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pilot_stage_h40(const IN* __restrict__ iq,
                                                               float* __restrict__ m_out,
                                                               float* __restrict__ p_out, int64_t n,
                                                               PilotTaps taps, float side_tap,
-                                                              unsigned tiles_x, unsigned batch) {
-    constexpr int H = 40, T = kPilotFastTile, PER = kPilotPer;
+                                                              unsigned tiles_x, unsigned batch, PilotBlocked blk) {
+    constexpr int H = 40, PER = kPilotPer, T = THREADS * PER;
+    const int Tv = BLK ? blk.rpt * blk.R : T;   // outputs this workgroup owns
     // m[q0 + e] lives at mpos(e): 8 values, 2 pad dwords.  The FIR reads each thread's window (thread tid
     // starts at e = 8 tid) with ds_read_b64: at a lane stride of 8 dwords those were 8-way bank conflicts
     // (SQ_LDS_BANK_CONFLICT = 69 % of the LDS cycles); at 10 dwords the 64 lanes x 2 dwords spread evenly.
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
     const int c = (int)(vid / tiles_x);
     const int tid = threadIdx.x;
     const int n32 = (int)n;
-    const int t0 = (int)(vid - (unsigned)c * tiles_x) * T;
+    const int t0 = (int)(vid - (unsigned)c * tiles_x) * Tv;
     const int q0 = t0 - H;
     const IN* xc = iq + (int64_t)c * n;
     // workgroup-uniform: the tile and its halos lie strictly inside the channel (no wrap, no reflection)
@@ -318,27 +324,27 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
     // discriminator: both samples of every pair are fetched unconditionally (clamped index) and
     // up front, 18 loads in flight per thread; a load inside the loop's `if` would serialise
     // one HBM round trip per iteration
-    constexpr int ND = (T + 2 * H + 2 + kThreads - 1) / kThreads;
+    constexpr int ND = (T + 2 * H + 2 + THREADS - 1) / THREADS;
     IN xa[ND], xb[ND];
     if (interior) {
         const IN* x0 = xc + (q0 - 1 + tid);
 #pragma unroll
         for (int it = 0; it < ND; ++it) {
             // the last sweep is ragged: clamp instead of branching (the value is not stored)
-            const int off = (it == ND - 1 && tid + kThreads * it >= T + 2 * H + 2) ? 0 : kThreads * it;
+            const int off = (it == ND - 1 && tid + THREADS * it >= T + 2 * H + 2) ? 0 : THREADS * it;
             xa[it] = x0[off];
             xb[it] = x0[off - 1];
         }
 #pragma unroll
         for (int it = 0; it < ND; ++it) {
-            const int s = tid + kThreads * it;
+            const int s = tid + THREADS * it;
             const float v = phase_step_fast(xa[it], xb[it]);
             if (it < ND - 1 || s < T + 2 * H + 2) d_s[s] = v;
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < (T + 2 * H + kThreads - 1) / kThreads; ++it) {
-            const int s = tid + kThreads * it;
+        for (int it = 0; it < (T + 2 * H + THREADS - 1) / THREADS; ++it) {
+            const int s = tid + THREADS * it;
             if (s < T + 2 * H) {
                 m_s[mpos(s)] = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
             }
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
     } else {
 #pragma unroll
         for (int it = 0; it < ND; ++it) {
-            int i = q0 - 1 + tid + kThreads * it;
+            int i = q0 - 1 + tid + THREADS * it;
             if (i == -1) i = n32 - 1;   // the same-size Decimate is circular (decimate.py:48)
             if (i == n32) i = 0;
             i = i < 1 ? 1 : (i > n32 - 1 ? n32 - 1 : i);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
         }
 #pragma unroll
         for (int it = 0; it < ND; ++it) {
-            const int s = tid + kThreads * it;
+            const int s = tid + THREADS * it;
             const int i = q0 - 1 + s;
             // d[0] = 0 (fm.py:64); i == n wraps to d[0]; outside [-1, n] is never read
             const bool live = (i == -1) || (i > 0 && i < n32);
@@ -363,12 +369,12 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
             if (s < T + 2 * H + 2) d_s[s] = v;
         }
         __syncthreads();
-        for (int s = tid; s < T + 2 * H; s += kThreads) {
+        for (int s = tid; s < T + 2 * H; s += THREADS) {
             const int q = q0 + s;
             float v = 0.f;
             if (q >= 0 && q < n32) {
                 v = 0.54f * d_s[s + 1] + side_tap * (d_s[s] + d_s[s + 2]);
-                if (q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
+                if (!BLK && q >= t0 && q < t0 + T) m_out[(int64_t)c * n + q] = v;
             }
             m_s[mpos(s)] = v;
         }
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
     // With each thread storing its own 8 outputs as two float4s, every line was completed by two instructions and the
     // L2 had to merge the halves.
     const int wbase = (tid >> 6) * (64 * PER), lane4 = (tid & 63) * 4;
-    if (interior) {
+    if (!BLK && interior) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int pos = wbase + h * (32 * PER) + lane4;                    // H + pos is a multiple of 4: one 8-group
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
     if (reflect) {
         const float m_first = (q0 <= 0) ? m_s[mpos(0 - q0)] : 0.f;
         const float m_last = (last - q0 < T + 2 * H) ? m_s[mpos(last - q0)] : 0.f;
-        for (int s = tid; s < T + 2 * H; s += kThreads) {
+        for (int s = tid; s < T + 2 * H; s += THREADS) {
             const int q = q0 + s;
             if (q < 0) m_s[mpos(s)] = 2.f * m_first - m_s[mpos(-q - q0)];
             else if (q > last && q <= last + H) m_s[mpos(s)] = 2.f * m_last - m_s[mpos(2 * last - q - q0)];
@@ -445,7 +451,38 @@ __global__ __launch_bounds__(kThreads) void k_pilot_stage_h40(const IN* __restri
                 wo[0] = wpair(H - 1 - j);
             }
         }
-        if (inner_tile || t0 + T <= n32) {   // (workgroup-uniform) the whole tile lies inside the channel
+        if constexpr (BLK) {
+            // p through d_s (dead since m_s was built), m is still in m_s.  One 128-byte line = rows k, k + 1 of a
+            // 16-column block = 8 lanes x float4: slot sl -> line sl / 8 = (block, row pair), a block's row pairs being
+            // adjacent lines; part sl % 8.  The index arithmetic is 32-bit with a multiply-high for the one division:
+            // this stage is VALU co-bound, and two 64-bit divisions per store cost it 0.07 ms.
+            float4* stage = reinterpret_cast<float4*>(&d_s[o]);
+            stage[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
+            stage[1] = make_float4(acc[4].x + acc[4].y, acc[5].x + acc[5].y, acc[6].x + acc[6].y, acc[7].x + acc[7].y);
+            __syncthreads();
+            const unsigned half = (unsigned)blk.rpt >> 1, k0 = (vid - (unsigned)c * tiles_x) * (unsigned)blk.rpt;
+            const unsigned nslots = half * (unsigned)blk.nb * 8u;
+            float* mc = m_out + (int64_t)c * blk.stride;
+            float* pc = p_out + (int64_t)c * blk.stride;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {   // rpt R <= 2048 outputs + the padding of each row's last block: <= 3 sweeps
+                const unsigned sl = (unsigned)tid + (unsigned)(THREADS * it);
+                if (sl < nslots) {
+                    const unsigned part = sl & 3u, lb = sl >> 3;
+                    const unsigned b = half == 1u ? lb : __umulhi(lb, blk.half_magic), rp = lb - b * half;   // (2^32 / 1 has no 32-bit magic)
+                    const unsigned r = 2u * rp + ((sl >> 2) & 1u), i = 16u * b + 4u * part;
+                    if (i < (unsigned)blk.R && k0 + r < (unsigned)blk.L) {
+                        const unsigned pos = r * (unsigned)blk.R + i;   // a multiple of 4: one 8-group of m_s
+                        const unsigned off = b * (unsigned)blk.bs + (k0 + r) * 16u + 4u * part;
+                        const v2f* src = reinterpret_cast<const v2f*>(&m_s[mpos(H + (int)pos)]);
+                        *reinterpret_cast<float4*>(mc + off) = make_float4(src[0].x, src[0].y, src[1].x, src[1].y);
+                        using v4 = __attribute__((ext_vector_type(4))) float;
+                        // non-temporal: the pair FFT's first pass, which reads p next, measured 0.01-0.02 ms faster
+                        __builtin_nontemporal_store(*reinterpret_cast<const v4*>(&d_s[pos]), reinterpret_cast<v4*>(pc + off));
+                    }
+                }
+            }
+        } else if (inner_tile || t0 + T <= n32) {   // (workgroup-uniform) the whole tile lies inside the channel
             // through d_s (dead since m_s was built): thread order in, lane-contiguous order out
             float4* stage = reinterpret_cast<float4*>(&d_s[o]);
             stage[0] = make_float4(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y, acc[3].x + acc[3].y);
@@ -888,7 +925,7 @@ void launch_discriminator(const float2* iq, float* d, int64_t n, int batch, hipS
 
 template <class IN>
 static void launch_pilot_stage_h40_t(const IN* iq, float* m_out, float* p_out, int64_t n, int batch,
-                                     const float* g_host, float side_tap, hipStream_t stream) {
+                                     const float* g_host, float side_tap, hipStream_t stream, const PilotBlocked* blk) {
     if (batch <= 0) return;
     PilotTaps taps;   // h[t] = g[|t - 40|], t = 0..80, h[81] = 0
     for (int j = 0; j <= 40; ++j) {
@@ -896,21 +933,48 @@ static void launch_pilot_stage_h40_t(const IN* iq, float* m_out, float* p_out, i
         taps.pair[j].x = g_host[t0 >= 40 ? t0 - 40 : 40 - t0];
         taps.pair[j].y = t1 <= 80 ? g_host[t1 >= 40 ? t1 - 40 : 40 - t1] : 0.f;
     }
+    if (blk && blk->valid()) {
+        RC_REQUIRE((int64_t)blk->L * blk->R == n && blk->rpt * blk->R <= kPilotBlockedTile && blk->R % 4 == 0, RCFM_ERR_ARG,
+                   "tile-blocked pilot layout does not match the signal");
+        const unsigned tiles_x = (unsigned)((blk->L + blk->rpt - 1) / blk->rpt);
+        const unsigned blocks = (tiles_x * (unsigned)batch + 7u) / 8u * 8u;
+        hipLaunchKernelGGL((k_pilot_stage_h40<IN, true, kPilotBlockedThreads>), dim3(blocks), dim3(kPilotBlockedThreads), 0, stream,
+                           iq, m_out, p_out, n, taps, side_tap, tiles_x, (unsigned)batch, *blk);
+        RC_LAUNCH_CHECK();
+        return;
+    }
     const unsigned tiles_x = (unsigned)((n + kPilotFastTile - 1) / kPilotFastTile);
     const unsigned blocks = (tiles_x * (unsigned)batch + 7u) / 8u * 8u;
-    hipLaunchKernelGGL(k_pilot_stage_h40<IN>, dim3(blocks), dim3(kThreads), 0, stream, iq, m_out, p_out, n, taps,
-                       side_tap, tiles_x, (unsigned)batch);
+    hipLaunchKernelGGL((k_pilot_stage_h40<IN, false, kThreads>), dim3(blocks), dim3(kThreads), 0, stream, iq, m_out, p_out, n, taps,
+                       side_tap, tiles_x, (unsigned)batch, PilotBlocked{});
     RC_LAUNCH_CHECK();
 }
 
+PilotBlocked PilotBlocked::plan(int64_t L, int64_t R) {
+    PilotBlocked b;
+    constexpr int T = kPilotBlockedTile;
+    // R >= 32: at most three store sweeps per workgroup (the padding of every row's last block counts)
+    if (R < 32 || L <= 0 || R % 4 != 0 || R > T / 2 || L * R > (int64_t)1 << 30) return b;
+    const int rpt = (int)(T / R) & ~1;
+    if (rpt < 2 || rpt * R < T - T / 8 || L * R < 2 * T) return b;
+    b.R = (int)R;
+    b.L = (int)L;
+    b.rpt = rpt;
+    b.nb = (int)((R + 15) / 16);
+    b.bs = (int)(16 * L);   // (an odd number of lines per block measured the same)
+    b.half_magic = (unsigned)((((uint64_t)1 << 32) + (rpt / 2) - 1) / (uint64_t)(rpt / 2));   // exact for lb < 2^16
+    b.stride = (int64_t)b.nb * b.bs;
+    return b;
+}
+
 void launch_pilot_stage_h40(const float2* iq, float* m_out, float* p_out, int64_t n, int batch,
-                            const float* g_host, float side_tap, hipStream_t stream) {
-    launch_pilot_stage_h40_t(iq, m_out, p_out, n, batch, g_host, side_tap, stream);
+                            const float* g_host, float side_tap, hipStream_t stream, const PilotBlocked* blk) {
+    launch_pilot_stage_h40_t(iq, m_out, p_out, n, batch, g_host, side_tap, stream, blk);
 }
 
 void launch_pilot_stage_h40_phase(const float* theta, float* m_out, float* p_out, int64_t n, int batch,
-                                  const float* g_host, float side_tap, hipStream_t stream) {
-    launch_pilot_stage_h40_t(theta, m_out, p_out, n, batch, g_host, side_tap, stream);
+                                  const float* g_host, float side_tap, hipStream_t stream, const PilotBlocked* blk) {
+    launch_pilot_stage_h40_t(theta, m_out, p_out, n, batch, g_host, side_tap, stream, blk);
 }
 
 void launch_pilot_stage(const float2* iq, const float* x, float* m_out, float* p_out, int64_t n,

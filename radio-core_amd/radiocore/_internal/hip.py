@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("RCFM_LIB") or os.path.join(os.path.dirname(_HERE), "_
 
 RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
 RCFM_OPT_LDS_CHAIN, RCFM_OPT_FUSED_TILES, RCFM_OPT_PHASE_LINK, RCFM_OPT_NARROW_TILES, RCFM_OPT_STATE_FENCE = 1, 2, 3, 4, 5   # rcfm_demod_set_option
-RCFM_OPT_PILOT_CHAIN, RCFM_OPT_DECIM_TILE, RCFM_OPT_LDS_DEEMPH = 6, 7, 8
+RCFM_OPT_PILOT_CHAIN, RCFM_OPT_DECIM_TILE, RCFM_OPT_LDS_DEEMPH, RCFM_OPT_PILOT_BLOCKED = 6, 7, 8, 9
 RCFM_TUNER_OPT_NARROW_TILES = 1                                                                                                # rcfm_tuner_set_option
 
 _ERR_SIZE, _ERR_INDEX, _ERR_RUNTIME, _ERR_ARG, _ERR_STATE = -1, -2, -3, -4, -5
