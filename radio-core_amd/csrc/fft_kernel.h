@@ -555,8 +555,13 @@ __device__ __forceinline__ void twiddle_powers(float2 w1, float2* pw) {
 
 // Middle stage: LDS -> LDS.  MT = block length entering the stage.
 // GTW: `tw` is the table in global memory and the q-th twiddle is a power of entry kp * step (twiddle_powers).
-template <int L, int R, int MT, bool SWZ, int RG, bool P17 = true, bool GTW = false>
+// ZQ > 0 (first stage only, MT == L): the rows from ZQ * m on hold zeros that nobody wrote -- inputs q >= ZQ of every
+// butterfly are literal zeros: no LDS write and no LDS read for them (a tenth of the mask tile's LDS traffic; the
+// butterflies themselves are packed inline assembly and a radix-5 kernel with two or three live inputs is no cheaper
+// than a full one, so the arithmetic stays: cfg4 -0.1...0.2 %).
+template <int L, int R, int MT, bool SWZ, int RG, bool P17 = true, bool GTW = false, int ZQ = 0>
 __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w, int rg) {
+    static_assert(ZQ == 0 || MT == L, "zero rows are declared for the first stage only");
     constexpr int m = MT / R, step = L / MT, rows = L / R, nit = (rows + RG - 1) / RG;
 #pragma unroll
     for (int it = 0; it < nit; ++it) {
@@ -568,7 +573,10 @@ __device__ __forceinline__ void stage_lds(float2* tile, const float2* tw, int w,
             float2 pw[GTW ? R : 1];
             if constexpr (GTW) pw[0] = tw[kp * step];   // issued ahead of the LDS reads it will meet
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = tile[lds_slot<SWZ, P17>(base + q * m, w)];
+            for (int q = 0; q < R; ++q) {
+                if (ZQ > 0 && q >= ZQ) v[q] = make_float2(0.f, 0.f);
+                else v[q] = tile[lds_slot<SWZ, P17>(base + q * m, w)];
+            }
             dft_p<R>(v);
             if constexpr (GTW) {
                 twiddle_powers<R>(pw[0], pw);
@@ -853,6 +861,10 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
     constexpr int RG = T / W;
     constexpr int nld = (L * W + T - 1) / T;
     constexpr int rowsL = L / RL, nitL = (rowsL + RG - 1) / RG;
+    // one-sided point-wise stages (kUpperRowsZero): input q of the second transform's first-stage butterflies covers the
+    // rows [q m, (q + 1) m), m = L / R0; from q = kZeroQ on all of them lie above L / 2 and are zero
+    constexpr int kZeroQ = mid_upper_rows_zero<MidOp>::value ? (L / 2) / (L / R0) + 1 : 0;
+    constexpr int kZeroFrom = kZeroQ > 0 && kZeroQ < R0 ? kZeroQ * (L / R0) : L;
     __shared__ __attribute__((aligned(16))) float2 tile[L * kRowsPitch];
     __shared__ __attribute__((aligned(16))) float2 tw[L];
     const FftPass& p1 = d1.p;
@@ -961,10 +973,11 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
                 const int k = kb + (L / RL) * q;
                 // A MidOp that declares kUpperRowsZero maps every row k > L / 2 to zero (one-sided spectra).  kb < L / RL,
                 // so the rows of this q start at (L / RL) q: decided at compile time, and the outputs of the last-stage
-                // butterfly that nobody reads are not computed at all (dead code in the unrolled DFT).
+                // butterfly that nobody reads are not computed at all (dead code in the unrolled DFT).  Rows from
+                // kZeroFrom on are not even written: the second transform's first stage takes them as literal zeros.
                 if constexpr (mid_upper_rows_zero<MidOp>::value) {
                     if ((L / RL) * q > L / 2) {
-                        tile[lds_slot<true>(k, w)] = make_float2(0.f, 0.f);
+                        if ((L / RL) * q < kZeroFrom) tile[lds_slot<true>(k, w)] = make_float2(0.f, 0.f);
                         continue;
                     }
                 }
@@ -976,7 +989,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
     lds_barrier();
 
     // ---- second transform: a strided pass of plan 2 whose input already sits in LDS ----------
-    stage_lds<L, R0, L, true, RG>(tile, tw, w, rg);
+    stage_lds<L, R0, L, true, RG, true, false, kZeroQ>(tile, tw, w, rg);
     lds_barrier();
     if constexpr (S >= 3) {
         stage_lds<L, R1, L / R0, true, RG>(tile, tw, w, rg);
