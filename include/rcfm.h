@@ -220,6 +220,10 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
 enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5,
        RCFM_OPT_PILOT_CHAIN = 6, RCFM_OPT_DECIM_TILE = 7, RCFM_OPT_LDS_DEEMPH = 8, RCFM_OPT_PILOT_BLOCKED = 9 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
+/* Reads an option back.  RCFM_OPT_PILOT_BLOCKED reads the EFFECTIVE value: 1 only when the switch is on AND this handle's
+ * geometry has the layout and the three-launch pilot chain that reads it (what a test needs to know that it compared two
+ * different forms).  No reference counterpart. */
+int rcfm_demod_get_option(rcfm_demod_t d, int option, int* value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 
 /* Whole hot path for one wideband buffer already loaded with rcfm_tuner_load:

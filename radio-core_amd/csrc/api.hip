@@ -1567,6 +1567,28 @@ int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
     });
 }
 
+int rcfm_demod_get_option(rcfm_demod_t d, int option, int* value) {
+    return guarded([&] {
+        RC_REQUIRE(d && value, RCFM_ERR_ARG, "NULL handle or output");
+        switch (option) {
+            case RCFM_OPT_LDS_CHAIN: *value = d->opt_lds_chain; break;
+            case RCFM_OPT_FUSED_TILES: *value = d->opt_pilot_chain && d->opt_decim_tile; break;
+            case RCFM_OPT_PILOT_CHAIN: *value = d->opt_pilot_chain; break;
+            case RCFM_OPT_DECIM_TILE: *value = d->opt_decim_tile; break;
+            // the EFFECTIVE value: the switch is on and this handle's geometry has the layout (and the chain that reads it)
+            case RCFM_OPT_PILOT_BLOCKED:
+                *value = d->opt_pilot_blocked && d->opt_pilot_chain && d->pilot_blocked().valid() &&
+                         fused_pilot_chain_applies(*d->eng_B, *d->eng_Bi, 2);
+                break;
+            case RCFM_OPT_LDS_DEEMPH: *value = d->opt_lds_deemph; break;
+            case RCFM_OPT_PHASE_LINK: *value = d->opt_phase_link; break;
+            case RCFM_OPT_NARROW_TILES: *value = d->opt_narrow; break;
+            case RCFM_OPT_STATE_FENCE: *value = d->state_buf->armed; break;
+            default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown demodulator option");
+        }
+    });
+}
+
 int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_host) {
     return guarded([&] {
         RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");

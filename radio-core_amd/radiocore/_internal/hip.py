@@ -71,6 +71,7 @@ SIGNATURES = {
     "rcfm_demod_get_taps": [_vp, _fp, _fp],
     "rcfm_demod_bind_state": [_vp, _vp, _i, _i, _vp],
     "rcfm_demod_set_option": [_vp, _i, _i],
+    "rcfm_demod_get_option": [_vp, _i, ctypes.POINTER(_i)],
     "rcfm_demod_destroy": [_vp],
     "rcfm_pipeline_run": [_vp, _vp, _i, _i, _vp, _vp],
     "rcfm_host_register": [_vp, _sz],
