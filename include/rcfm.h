@@ -23,6 +23,9 @@
  *     routes every transform through rocFFT (safety net and A/B partner; the
  *     default is the hand-written engine, rocFFT only for lengths outside it).
  *     Every other choice is an argument or a *_set_option of a handle;
+ *   - this header is what a HOST binds (tuner, demodulators, pipeline, ingest, gather, primitives, plain FFT).  The
+ *     entry points that exist for the repo's own tools and tests -- placement arenas, explicit FFT plans, the
+ *     kernel-form switches, per-stage profiling -- are declared in rcfm_tools.h (same library, same conventions);
  *   - batched arrays are channel-major and contiguous: iq [C][B] complex64,
  *     audio [C][A][ch] float32 (ch = 1 for FM/MFM, 2 = interleaved L,R for WBFM,
  *     the byte layout of the reference's (1, A, 2) array, wbfm.py:94).
@@ -37,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RCFM_VERSION 101 /* 0.1.1: rcfm_fft_pass grew in_t / out_t */
+#define RCFM_VERSION 102 /* 0.1.2: tooling entry points moved to rcfm_tools.h (same symbols), RCFM_OPT_GRAPH */
 
 typedef enum rcfm_status {
     RCFM_OK = 0,
@@ -59,7 +62,6 @@ typedef struct rcfm_demod_s* rcfm_demod_t;
 typedef struct rcfm_resampler_s* rcfm_resampler_t;
 typedef struct rcfm_feeder_s* rcfm_feeder_t;
 typedef struct rcfm_comm_s* rcfm_comm_t;
-typedef struct rcfm_arena_s* rcfm_arena_t;
 
 /* ---- library / device ---------------------------------------------------- */
 
@@ -80,30 +82,6 @@ int rcfm_stream_sync(void* stream);
  * one (or any hipStream_t, or NULL for the default stream). */
 int rcfm_stream_create(void** stream);
 int rcfm_stream_destroy(void* stream);
-
-/* ---- placement of the library's workspaces (no reference counterpart: numpy / cupy allocate per call) ------------
- * Where hipMalloc puts a multi-GB workspace moves the kernels that stream through it by 1.5 - 4 % of a cfg4 buffer, and
- * the draw differs from handle to handle and from process to process (profiles/r04_k_placement.md).  A host that wants
- * ONE draw for a whole handle set, or wants to choose it (create several arenas, time its own workload in each, keep
- * the best), creates an arena: device memory taken in blocks of `block_bytes` (0: 1 GiB blocks, taken on demand; a
- * request larger than a block gets a block of its own) and handed out by a bump pointer on 2 MiB boundaries.
- *   bind      arena != NULL: tuner / demodulator handles CREATED by this thread from now on belong to the arena -- every
- *             workspace of 1 MiB or more they ever allocate (at creation and later, whichever thread calls) comes from
- *             it; NULL: back to hipMalloc per workspace (the default; existing handles keep their arena)
- *   stats     bytes reserved from the device, bytes handed out, pieces still owned by live handles
- *   destroy   RCFM_ERR_STATE while a handle created inside the arena is alive (pieces return with the arena, not one
- *             by one: a handle set that is rebuilt often should get a fresh arena)
- * Results do not depend on any of this.  bench.py --arena 1, tools/placement_sets.py. */
-int rcfm_arena_create(size_t block_bytes, rcfm_arena_t* out);
-/* The same over memory the HOST owns (a block of its own allocator -- a torch tensor, an rcfm_malloc block): the
- * library's workspaces then live where the host decided, and two handle sets built one after the other inside arenas
- * over the same block get the same addresses (tools/ab_libs.py compares two builds of the library that way, free of
- * placement noise).  The memory must outlive the arena; it is not freed by rcfm_arena_destroy.  What does not fit comes
- * from hipMalloc. */
-int rcfm_arena_adopt(void* base, size_t bytes, rcfm_arena_t* out);
-int rcfm_arena_bind(rcfm_arena_t arena);
-int rcfm_arena_stats(rcfm_arena_t arena, size_t* reserved_bytes, size_t* used_bytes, size_t* live_pieces);
-int rcfm_arena_destroy(rcfm_arena_t arena);
 
 /* ---- Tuner (radiocore/tools/tuner.py) ------------------------------------ */
 
@@ -153,10 +131,6 @@ int rcfm_tuner_window(rcfm_tuner_t t, int first, int count, int64_t* first_bin, 
 int rcfm_tuner_window_layout(rcfm_tuner_t t, int first, int count, int64_t* halo, int64_t* nbins);
 int rcfm_tuner_attach_window(rcfm_tuner_t t, void* storage, int first, int count);
 int rcfm_tuner_adopt(rcfm_tuner_t t, int first, int count, void* stream);
-/* Which tile width rcfm_tuner_run uses (rcfm_pipeline_run passes the demodulator's RCFM_OPT_NARROW_TILES instead):
- * 0 = always 16 lines per tile, 1 (default) = 8 when a launch has fewer than two 16-line tiles per CU, 2 = always 8. */
-enum { RCFM_TUNER_OPT_NARROW_TILES = 1 };
-int rcfm_tuner_set_option(rcfm_tuner_t t, int option, int value);
 int rcfm_tuner_destroy(rcfm_tuner_t t);
 
 /* ---- demodulators (radiocore/analog/{fm,mfm,wbfm}.py) --------------------- */
@@ -188,27 +162,11 @@ int rcfm_demod_get_taps(rcfm_demod_t d, float* deemph51_host, float* pilot41_hos
  * `single` may itself hold several channels (slots [index, index + its C) are taken: two batched handles of one
  * geometry then share one state).  Same class, audio rate and time constant required; FM has no state (no-op). */
 int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, int move_history, void* stream);
-/* Which forms of the chain a handle may use (no reference counterpart: the reference has one form of everything).
- * All default to 1.  The results do not depend on them beyond float32 rounding -- tests/test_hip_configs.py compares
- * every channel of a full-size buffer between the default handle and one with all three switched off, which shares no
- * kernel schedule with it.
- *   RCFM_OPT_LDS_CHAIN    narrow FM / MFM channels run tuner + demodulator of a channel pair in one workgroup (0: the
- *                         multi-pass launches)
- *   RCFM_OPT_FUSED_TILES  two transforms per tile: pilot chain, Hilbert mask, stereo mix, spectral decimation between
- *                         transforms (0: one transform per launch, the intermediate spectra go through memory); sets
- *                         the two switches below together
- *   RCFM_OPT_PILOT_CHAIN  ... only the tiles around the Hilbert mask (pilot pair FFT -> mask -> IFFT -> stereo matrix)
- *   RCFM_OPT_DECIM_TILE   ... only the spectral decimation between FFT_B's last pass and IFFT_A's first
- *   RCFM_OPT_PILOT_BLOCKED WBFM's mono signal and pilot band travel from the pilot stage to the pilot chain in a tile-blocked
- *                         layout (the chain's 16-line tiles read contiguous runs; 0: natural order, half-line reads)
- *   RCFM_OPT_LDS_DEEMPH   narrow MFM channels: de-emphasis, mean removal and clip inside the LDS chain (0: the
- *                         de-emphasis launches behind it)
- *   RCFM_OPT_PHASE_LINK   the tuner hands the demodulator angle(x) / pi as float32 (0: complex64 samples, as
- *                         tuner.py:161 returns them)
+/* Per-handle options a HOST may need (the kernel-form switches that tools and tests use live in rcfm_tools.h).
  *   RCFM_OPT_NARROW_TILES the tile kernels exist with 16 and with 8 lines per tile: 0 = always 16, 1 (default) = 8 when a
- *                         launch has fewer than two 16-line tiles per CU; applies to the demodulator's kernels and, in
- *                         rcfm_pipeline_run, to the tuner's inverse FFT of the same chunk (one WBFM.run per call, the reference's harness
- *                         shape tests/benchmark.py:29-31: 60 short tiles instead of 30 long ones), 2 = always 8
+ *                         launch has fewer than two 16-line tiles per CU (one WBFM.run per call, the reference's harness
+ *                         shape tests/benchmark.py:29-31: 60 short tiles instead of 30 long ones), 2 = always 8; applies
+ *                         to the demodulator's kernels and, in rcfm_pipeline_run, to the tuner's inverse FFT of the chunk
  *   RCFM_OPT_STATE_FENCE  (default 0) consecutive buffers on DIFFERENT streams: the reference's loop
  *                         (examples/multi_fm_server.py:98-106) handles one buffer at a time; a host that keeps two handle
  *                         sets (tuner + demodulator, the second demodulator bound to the first one's state with
@@ -216,14 +174,13 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *                         i + 1 fill the gaps of buffer i.  The de-emphasis state is the one thing buffer i + 1 needs
  *                         from buffer i (deemphasis.py:64): with the fence on, every launch sequence that touches the
  *                         shared state waits for the event the previous one recorded, on whichever stream that was.
- *                         Set it on any ONE handle of the sharing group, after the binding */
-enum { RCFM_OPT_LDS_CHAIN = 1, RCFM_OPT_FUSED_TILES = 2, RCFM_OPT_PHASE_LINK = 3, RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5,
-       RCFM_OPT_PILOT_CHAIN = 6, RCFM_OPT_DECIM_TILE = 7, RCFM_OPT_LDS_DEEMPH = 8, RCFM_OPT_PILOT_BLOCKED = 9 };
+ *                         Set it on any ONE handle of the sharing group, after the binding
+ *   RCFM_OPT_GRAPH        (default 1) a handle of ONE channel (the reference's per-channel call, fm.py:46 / mfm.py:51 /
+ *                         wbfm.py:66; tests/benchmark.py:29-31 times exactly these) replays its launch chain from a
+ *                         captured hipGraph when the call's pointers and stream kind repeat: one graph launch instead of
+ *                         ten kernel launches.  0: plain launches.  Results are bit-identical either way */
+enum { RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5, RCFM_OPT_GRAPH = 10 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
-/* Reads an option back.  RCFM_OPT_PILOT_BLOCKED reads the EFFECTIVE value: 1 only when the switch is on AND this handle's
- * geometry has the layout and the three-launch pilot chain that reads it (what a test needs to know that it compared two
- * different forms).  No reference counterpart. */
-int rcfm_demod_get_option(rcfm_demod_t d, int option, int* value);
 int rcfm_demod_destroy(rcfm_demod_t d);
 
 /* Whole hot path for one wideband buffer already loaded with rcfm_tuner_load:
@@ -319,55 +276,9 @@ int rcfm_discriminator(int C, int n, const void* iq, void* d, void* stream);
 
 /* ---- FFT engine (the hand-written replacement of cupy.fft / scipy.fft calls) -- */
 
-/* Describes how librcfm runs a length-n complex FFT: fills a POD `rcfm_fft_plan`
- * (layout below) and returns 0, or RCFM_ERR_ARG when n is outside the engine
- * (radices other than 2/3/5, n < 256, more than 4 passes): such lengths use rocFFT. */
-typedef struct rcfm_fft_pass {
-    int32_t L, nstages, radix[8];
-    int64_t n_o1, n_o2, n_inner;
-    int64_t in_o1, in_o2, in_i, in_l;
-    int64_t out_o1, out_o2, out_i, out_k;
-    int64_t tw_o1, tw_o2, tw_i;
-    int32_t has_twiddle, load_along_l;
-    int64_t in_t, out_t; /* tile-blocked hand-over between strided passes: element offset of tile t (16 lines) = t * in_t /
-                            t * out_t; 0 = the plain layout (16 * in_i, 16) */
-} rcfm_fft_pass;
-typedef struct rcfm_fft_plan {
-    int64_t n;
-    int32_t npass, fine_bits;
-    int64_t tmp_stride; /* scratch elements per signal between passes (>= n) */
-    rcfm_fft_pass pass[4];
-} rcfm_fft_plan;
-int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);
-/* The plan for given pass lengths (what rcfm_fft_c2c_plan runs).  blocked: the tile-blocked hand-over between the first two
- * passes of a three-pass plan: -1 = as the engine decides (transforms beyond the Infinity Cache), 0 = never, 1 = whenever
- * the lengths allow it (tests/test_fft_plan.py models it at small n). */
-int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int blocked, rcfm_fft_plan* plan);
 /* Unnormalised forward (inverse = 0) or conjugate (inverse = 1) transform of `batch`
  * contiguous length-n complex64 signals; in == out allowed.  (scipy.fft.fft / ifft*n) */
 int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);
-/* The same transform with the pass lengths given by the caller (their product is n, each within the engine's tile
- * lengths; RCFM_ERR_ARG otherwise): plan sweeps (tools/plan_sweep.py) and tests that put a tile length into a role the
- * planner does not use it in (tests/test_hip_fft.py). */
-int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int batch, int inverse, const void* in,
-                      void* out, void* stream);
-/* The same transform through rocFFT (any n): the A/B partner of rcfm_fft_c2c in
- * tools/bench_fft.py and the fallback for lengths the engine refuses. */
-int rcfm_fft_c2c_rocfft(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);
-
-/* ---- measurement ------------------------------------------------------------ */
-
-/* Per-stage timing with HIP events recorded on the stage's own stream (the reference
- * has only timeit around whole calls, tests/benchmark.py:22-24).  A stage is one
- * kernel launch or one FFT execute.  enable(mask): bit i switches stage i on;
- * read(): waits for the recorded events and returns the accumulated milliseconds
- * and the number of bracketed launches since the last reset. */
-int rcfm_profile_stage_count(void);
-const char* rcfm_profile_stage_name(int stage);
-int rcfm_profile_enable(uint64_t stage_mask);
-int rcfm_profile_reset(void);
-int rcfm_profile_read(int stage, double* total_ms, int64_t* launches);
-
 #ifdef __cplusplus
 }
 #endif

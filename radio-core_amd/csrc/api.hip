@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <tuple>
 #include <vector>
 
@@ -45,6 +46,8 @@ struct rcfm_arena_s {
     };
     std::vector<Block> blocks;
     size_t live = 0;                        // pieces handed out and not yet dropped
+    size_t handles = 0;                     // tuner / demodulator handles created inside (they keep the pointer for life,
+                                            // whether or not they hold a piece at the moment)
     ~rcfm_arena_s() {
         for (auto& b : blocks)
             if (b.owned) (void)hipFree(b.base);
@@ -53,11 +56,37 @@ struct rcfm_arena_s {
 namespace rcfm {
 
 namespace {
-thread_local Arena* g_arena = nullptr;
+// Two thread-local notions, on purpose apart: what the HOST bound (rcfm_arena_bind) is only ever read when a tuner or
+// demodulator handle is created; what an allocation draws from is the arena of the handle whose entry point is running
+// (ArenaScope).  Function-static scratch, plan caches and the resampler / feeder handles therefore never take a piece,
+// whatever is bound when they happen to allocate.
+thread_local Arena* g_bound = nullptr;
+thread_local Arena* g_scope = nullptr;
 constexpr size_t kArenaAlign = (size_t)2 << 20;   // pieces start on 2 MiB boundaries (the large-page size)
+std::mutex g_arenas_mu;
+std::set<Arena*> g_arenas;                        // arenas that exist (a binding left behind on another thread is checked)
 }  // namespace
 
-Arena* current_arena() { return g_arena; }
+Arena* current_arena() { return g_scope; }
+
+Arena* arena_enter_handle() {
+    Arena* a = g_bound;
+    if (!a) return nullptr;
+    std::lock_guard<std::mutex> reg(g_arenas_mu);
+    if (!g_arenas.count(a)) {   // destroyed on another thread while still bound here
+        g_bound = nullptr;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(a->mu);
+    a->handles += 1;
+    return a;
+}
+
+void arena_leave_handle(Arena* a) {
+    if (!a) return;
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (a->handles) a->handles -= 1;
+}
 
 void* arena_take(Arena* a, size_t bytes) {
     std::lock_guard<std::mutex> lock(a->mu);
@@ -82,8 +111,8 @@ void arena_drop(Arena* a) {
     if (a->live) a->live -= 1;
 }
 
-ArenaScope::ArenaScope(Arena* a) : prev(g_arena) { g_arena = a; }
-ArenaScope::~ArenaScope() { g_arena = prev; }
+ArenaScope::ArenaScope(Arena* a) : prev(g_scope) { g_scope = a; }
+ArenaScope::~ArenaScope() { g_scope = prev; }
 
 namespace {
 
@@ -332,7 +361,8 @@ static bool use_engine() {
 }
 
 struct rcfm_tuner_s {
-    Arena* arena = current_arena();   // rcfm_arena_bind at creation: every workspace of this handle, for its whole life
+    Arena* arena = arena_enter_handle();   // rcfm_arena_bind at creation: every workspace of this handle, for its whole life
+    ~rcfm_tuner_s() { arena_leave_handle(arena); }   // (the members drop their pieces after this body)
     int opt_narrow = kNarrowDefault;  // RCFM_TUNER_OPT_NARROW_TILES (rcfm_pipeline_run passes the demodulator's setting)
     int64_t n = 0;
     int nch = 0;
@@ -541,7 +571,12 @@ struct rcfm_tuner_s {
 };
 
 struct rcfm_demod_s {
-    Arena* arena = current_arena();   // rcfm_arena_bind at creation
+    Arena* arena = arena_enter_handle();   // rcfm_arena_bind at creation
+    ~rcfm_demod_s() {
+        drop_graphs();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        arena_leave_handle(arena);
+    }
     int kind = 0, C = 0, B = 0, A = 0, ch = 1, chunk = 1;
     double tau = 75e-6;
     float taps_h[51];
@@ -593,6 +628,29 @@ struct rcfm_demod_s {
     bool opt_phase_link = true;
     bool opt_lds_deemph = true;      // MFM's de-emphasis inside the LDS chain
     int opt_narrow = kNarrowDefault;   // RCFM_OPT_NARROW_TILES
+    // RCFM_OPT_GRAPH: one channel per call (the reference's per-channel demodulator.run, tests/benchmark.py:29-31) is ten
+    // launches of a few microseconds each: launch-bound.  The second call with the same pointers captures the chain
+    // into a hipGraph (the first one has warmed up every lazily built table and workspace, so the capture allocates
+    // nothing); later calls replay it with ONE graph launch on the caller's stream.  Same kernels, same arguments:
+    // bit-identical.  Not used while a stage timer or the state fence (events on the stream) is on.
+    bool opt_graph = true;
+    struct GraphSlot {
+        const void* iq;
+        void* audio;
+        const float* state;
+        int first;
+        hipGraphExec_t exec;
+        uint64_t used;
+    };
+    std::vector<GraphSlot> graphs;
+    GraphSlot last_call{nullptr, nullptr, nullptr, -1, nullptr, 0};
+    hipStream_t cap_stream = nullptr;
+    uint64_t graph_tick = 0;
+    void drop_graphs() {   // whatever the captured chains depended on has changed (option, state binding)
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+        last_call = GraphSlot{nullptr, nullptr, nullptr, -1, nullptr, 0};
+    }
     bool narrow(int cnt) const { return eng_B && narrow_launch(*eng_B, cnt, opt_narrow); }
     DeviceBuffer work, buf_iq, buf_m, buf_p, buf_P, buf_Z, buf_V, buf_v, partial, buf_T, buf_TA, buf_U2, buf_dc;
     int tiles = 0;
@@ -1183,6 +1241,10 @@ int rcfm_arena_create(size_t block_bytes, rcfm_arena_t* out) {
             RC_HIP(hipMalloc(&base, a->block_bytes));
             a->blocks.push_back(Arena::Block{static_cast<char*>(base), a->block_bytes, 0, true});
         }
+        {
+            std::lock_guard<std::mutex> reg(g_arenas_mu);
+            g_arenas.insert(a.get());
+        }
         *out = a.release();
     });
 }
@@ -1196,12 +1258,22 @@ int rcfm_arena_adopt(void* base, size_t bytes, rcfm_arena_t* out) {
         const size_t skew = (kArenaAlign - (reinterpret_cast<uintptr_t>(p) & (kArenaAlign - 1))) & (kArenaAlign - 1);
         RC_REQUIRE(bytes > skew + kArenaAlign, RCFM_ERR_ARG, "bad arena memory");
         a->blocks.push_back(Arena::Block{p + skew, (bytes - skew) / kArenaAlign * kArenaAlign, 0, false});
+        {
+            std::lock_guard<std::mutex> reg(g_arenas_mu);
+            g_arenas.insert(a.get());
+        }
         *out = a.release();
     });
 }
 
 int rcfm_arena_bind(rcfm_arena_t a) {
-    return guarded([&] { g_arena = a; });
+    return guarded([&] {
+        if (a) {
+            std::lock_guard<std::mutex> reg(g_arenas_mu);
+            RC_REQUIRE(g_arenas.count(a) != 0, RCFM_ERR_ARG, "not a live arena");
+        }
+        g_bound = a;
+    });
 }
 
 int rcfm_arena_stats(rcfm_arena_t a, size_t* reserved_bytes, size_t* used_bytes, size_t* live_pieces) {
@@ -1223,10 +1295,18 @@ int rcfm_arena_destroy(rcfm_arena_t a) {
     return guarded([&] {
         if (!a) return;
         {
-            std::lock_guard<std::mutex> lock(a->mu);
-            RC_REQUIRE(a->live == 0, RCFM_ERR_STATE, "handles created inside this arena are still alive: destroy them first");
+            std::lock_guard<std::mutex> reg(g_arenas_mu);
+            RC_REQUIRE(g_arenas.count(a) != 0, RCFM_ERR_ARG, "not a live arena");
+            {
+                // handles, not pieces: a tuner whose spectrum was attached, or a handle of small buffers only, holds no
+                // piece and still allocates from its arena on its next run
+                std::lock_guard<std::mutex> lock(a->mu);
+                RC_REQUIRE(a->handles == 0 && a->live == 0, RCFM_ERR_STATE,
+                           "handles created inside this arena are still alive: destroy them first");
+            }
+            g_arenas.erase(a);   // a binding another thread still holds is dropped when that thread next creates a handle
         }
-        if (g_arena == a) g_arena = nullptr;
+        if (g_bound == a) g_bound = nullptr;
         delete a;
     });
 }
@@ -1239,6 +1319,7 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
         RC_REQUIRE(n >= 1 && nch >= 0, RCFM_ERR_ARG, "bad tuner size");
         RC_REQUIRE(nch == 0 || (roll_host && bw_host), RCFM_ERR_ARG, "roll/bw is NULL");
         auto t = std::make_unique<rcfm_tuner_s>();
+        ArenaScope scope(t->arena);
         t->n = n;
         t->nch = nch;
         t->roll.resize(nch);
@@ -1435,6 +1516,7 @@ int rcfm_demod_create(int kind, int C, int B, int A, double tau, int chunk, rcfm
         RC_REQUIRE(kind >= RCFM_FM && kind <= RCFM_WBFM, RCFM_ERR_ARG, "unknown demodulator kind");
         RC_REQUIRE(C >= 1 && B >= 2 && A >= 1, RCFM_ERR_ARG, "bad demodulator size");
         auto d = std::make_unique<rcfm_demod_s>();
+        ArenaScope scope(d->arena);
         d->kind = kind;
         d->C = C;
         d->B = B;
@@ -1483,6 +1565,49 @@ int rcfm_demod_run(rcfm_demod_t d, int first, int count, const void* iq, void* a
         ArenaScope scope(d->arena);
         const float2* in = static_cast<const float2*>(iq);
         float* outp = static_cast<float*>(audio);
+        if (count == 1 && d->opt_graph && d->eng_B && g_prof.mask == 0 && !d->state_buf->armed) {
+            hipStream_t s = as_stream(stream);
+            const float* st = d->kind == RCFM_FM ? nullptr : d->state_ptr();
+            for (auto& g : d->graphs)
+                if (g.iq == iq && g.audio == audio && g.first == first && g.state == st) {
+                    g.used = ++d->graph_tick;
+                    RC_HIP(hipGraphLaunch(g.exec, s));
+                    return;
+                }
+            const auto& lc = d->last_call;
+            if (lc.iq == iq && lc.audio == audio && lc.first == first && lc.state == st) {
+                // second call in a row with these pointers: capture (on a stream of the handle's own) and replay
+                if (!d->cap_stream) RC_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                bool ok = hipStreamBeginCapture(d->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    try {
+                        d->run_chunk(first, 1, in, outp, d->cap_stream);
+                    } catch (...) {
+                        ok = false;
+                    }
+                    if (hipStreamEndCapture(d->cap_stream, &graph) != hipSuccess || graph == nullptr) ok = false;
+                }
+                if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                if (ok) {
+                    if (d->graphs.size() >= 8) {   // a host that rotates more than eight buffer pairs: least recently used goes
+                        size_t lru = 0;
+                        for (size_t i = 1; i < d->graphs.size(); ++i)
+                            if (d->graphs[i].used < d->graphs[lru].used) lru = i;
+                        (void)hipGraphExecDestroy(d->graphs[lru].exec);
+                        d->graphs.erase(d->graphs.begin() + (long)lru);
+                    }
+                    d->graphs.push_back(rcfm_demod_s::GraphSlot{iq, audio, st, first, exec, ++d->graph_tick});
+                    RC_HIP(hipGraphLaunch(exec, s));
+                    return;
+                }
+                d->opt_graph = false;   // this runtime cannot capture the chain: plain launches from now on
+            }
+            d->last_call = rcfm_demod_s::GraphSlot{iq, audio, st, first, nullptr, 0};
+        }
         for (int off = 0; off < count; off += d->chunk) {
             const int cnt = std::min(d->chunk, count - off);
             d->run_chunk(first + off, cnt, in + (size_t)off * d->B, outp + (size_t)off * d->A * d->ch,
@@ -1535,6 +1660,7 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
             RC_HIP(hipMemcpyAsync(dst, single->state_ptr(), per * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
             RC_HIP(hipStreamSynchronize(as_stream(stream)));   // the old buffer may be freed right below
         }
+        single->drop_graphs();
         single->state_buf = batched->state_buf;
         single->state_off = slot;
     });
@@ -1543,7 +1669,9 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value) {
     return guarded([&] {
         RC_REQUIRE(d, RCFM_ERR_ARG, "NULL handle");
+        d->drop_graphs();
         switch (option) {
+            case RCFM_OPT_GRAPH: d->opt_graph = value != 0; break;
             case RCFM_OPT_LDS_CHAIN: d->opt_lds_chain = value != 0; break;
             case RCFM_OPT_FUSED_TILES: d->opt_pilot_chain = d->opt_decim_tile = value != 0; break;
             case RCFM_OPT_PILOT_CHAIN: d->opt_pilot_chain = value != 0; break;
@@ -1584,6 +1712,8 @@ int rcfm_demod_get_option(rcfm_demod_t d, int option, int* value) {
             case RCFM_OPT_PHASE_LINK: *value = d->opt_phase_link; break;
             case RCFM_OPT_NARROW_TILES: *value = d->opt_narrow; break;
             case RCFM_OPT_STATE_FENCE: *value = d->state_buf->armed; break;
+            // 0 = off (or this runtime refused the capture), 1 = on, 1 + k = on and k captured chains are being replayed
+            case RCFM_OPT_GRAPH: *value = d->opt_graph ? 1 + (int)d->graphs.size() : 0; break;
             default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown demodulator option");
         }
     });

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "rcfm.h"
+#include "rcfm_tools.h"
 
 namespace rcfm {
 
@@ -54,10 +55,15 @@ int guarded(F&& body) {
 // Where hipMalloc puts a workspace moves the kernels that stream through it by several per cent
 // (profiles/r04_k_placement.md).  A caller who wants ONE draw for a whole handle set creates an arena -- a few large
 // device blocks, bump-allocated -- and binds it while the handles are created; every workspace of those handles of
-// kArenaMinBytes or more then comes from the arena, for the handles' whole life (lazy growth included).
+// kArenaMinBytes or more then comes from the arena, for the handles' whole life (lazy growth included).  Arena use is
+// opt-in per handle: only a tuner / demodulator handle adopts the bound arena, and a DeviceBuffer draws from an arena
+// only while such a handle's entry point runs (ArenaScope) -- function-static scratch, plan caches and the other handle
+// kinds always come from hipMalloc.
 using Arena = ::rcfm_arena_s;
 constexpr size_t kArenaMinBytes = (size_t)1 << 20;
-Arena* current_arena();                         // thread-local: the arena allocations of this thread draw from (or null)
+Arena* current_arena();                         // thread-local: the arena of the handle whose entry point is running (ArenaScope), or null
+Arena* arena_enter_handle();                    // a tuner / demodulator handle is being created: the arena the host bound (counted), or null
+void arena_leave_handle(Arena* a);              // ... and destroyed
 void* arena_take(Arena* a, size_t bytes);       // a piece of the arena (never null: the arena grows by whole blocks)
 void arena_drop(Arena* a);                      // a piece is no longer used (the bytes return when the arena goes)
 struct ArenaScope {                             // entry points of a handle run inside its arena

@@ -99,25 +99,35 @@ class FftEngine {
     // Same transform with the pass lengths given (e.g. the planner's two factors swapped, so that
     // this plan's last pass tiles exactly like another plan's first pass: fused_passes.h).
     FftEngine(int64_t n, const int64_t* factors, int nfactors);
+    // The plan in the PLAIN layout (every strided pass keeps the layout it reads: safe in place, what every fused caller
+    // of pass_dev() assumes).  desc_blocked() is the same plan with the tile-blocked hand-over between its first two
+    // passes (FftPass::in_t / out_t) when the planner chose one -- c2c() runs it only when no pass runs in place.
     const FftPlanDesc& desc() const { return desc_; }
+    bool has_blocked() const { return has_blk_; }
+    const FftPlanDesc& desc_blocked() const { return has_blk_ ? desc_blk_ : desc_; }
     int npass() const { return desc_.npass; }
     int64_t tmp_stride() const { return desc_.tmp_stride; }   // scratch elements per signal (>= n)
     // Unnormalised c2c transform of `batch` contiguous length-n signals (distance n).
     // `tmp` holds batch * tmp_stride() complex values; in == out is allowed, tmp must be distinct.
+    // A plan with a tile-blocked hand-over reads another address set in its second pass than it writes, so it runs only
+    // when in, out and tmp are three distinct arrays (no pass in place); otherwise the plain layout of the same plan runs.
     // inverse = conjugate transform (no 1/n); every output is multiplied by `scale`.
     // keep (forward transforms only): the last pass stores only those rows of the output; the rest of
     // `out` is left untouched.
     void c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
              hipStream_t stream, const FftRowWindow* keep = nullptr) const;
     int64_t row_length() const { return desc_.pass[0].L; }   // n_1
-    FftPassDev pass_dev(int t, int64_t in_batch, int64_t out_batch) const;
+    FftPassDev pass_dev(int t, int64_t in_batch, int64_t out_batch, bool blocked = false) const;
     static size_t lds_bytes(int L);
     static dim3 grid(const FftPass& p, int batch);
     static int compute_units();   // CUs of the current device (256 on MI355X)
 
    private:
     void build_tables();
-    FftPlanDesc desc_;
+    void split_layouts();
+    FftPlanDesc desc_;       // plain layout
+    FftPlanDesc desc_blk_;   // tile-blocked hand-over (valid when has_blk_)
+    bool has_blk_ = false;
     DeviceBuffer stage_tw_[kFftMaxPasses];
     DeviceBuffer pos_[kFftMaxPasses];
     DeviceBuffer coarse_;

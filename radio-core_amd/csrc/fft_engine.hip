@@ -287,14 +287,29 @@ int FftEngine::compute_units() {
 }
 
 FftEngine::FftEngine(int64_t n) {
-    RC_REQUIRE(fft_plan_describe(n, &desc_), RCFM_ERR_ARG, "length not supported by the FFT engine");
+    RC_REQUIRE(fft_plan_describe(n, &desc_blk_), RCFM_ERR_ARG, "length not supported by the FFT engine");
+    split_layouts();
     build_tables();
 }
 
 FftEngine::FftEngine(int64_t n, const int64_t* factors, int nfactors) {
-    RC_REQUIRE(fft_plan_describe(n, &desc_, 0, factors, nfactors), RCFM_ERR_ARG,
+    RC_REQUIRE(fft_plan_describe(n, &desc_blk_, 0, factors, nfactors), RCFM_ERR_ARG,
                "pass lengths not supported by the FFT engine");
+    split_layouts();
     build_tables();
+}
+
+// desc_blk_ holds what the planner chose; desc_ is the same plan (same pass lengths) in the plain layout.
+void FftEngine::split_layouts() {
+    has_blk_ = desc_blk_.npass == 3 && desc_blk_.pass[0].out_t != 0;
+    if (!has_blk_) {
+        desc_ = desc_blk_;
+        return;
+    }
+    int64_t f[kFftMaxPasses];
+    for (int t = 0; t < desc_blk_.npass; ++t) f[t] = desc_blk_.pass[t].L;
+    RC_REQUIRE(fft_plan_describe(desc_blk_.n, &desc_, 0, f, desc_blk_.npass, 0), RCFM_ERR_RUNTIME,
+               "plain layout of a blocked plan");
 }
 
 void FftEngine::build_tables() {
@@ -331,9 +346,9 @@ void FftEngine::build_tables() {
     coarse_.upload(coarse.data(), coarse.size() * sizeof(float2));
 }
 
-FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch) const {
+FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch, bool blocked) const {
     FftPassDev d;
-    d.p = desc_.pass[t];
+    d.p = (blocked && has_blk_) ? desc_blk_.pass[t] : desc_.pass[t];
     d.stage_tw = stage_tw_[t].as<float2>();
     d.pos = pos_[t].as<uint16_t>();
     d.coarse = coarse_.as<float2>();
@@ -360,6 +375,8 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
     // in or tmp the old routing stays.
     const bool ping_pong = np >= 3 && ts == n && in != out && out != tmp && in != tmp &&
                            (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20);
+    // The tile-blocked hand-over (pass 1 reads another address set than it writes) only when no pass runs in place.
+    const bool blk = ping_pong && has_blk_;
     auto mid = [&](int t) -> float2* {   // where pass t < np - 1 writes
         if (!ping_pong) return tmp;
         return ((np - 2 - t) & 1) ? out : tmp;
@@ -367,7 +384,7 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
     for (int t = 0; t < np; ++t) {
         const bool first = (t == 0), last = (t == np - 1);
         const float2* src = first ? in : mid(t - 1);
-        const FftPassDev dev = pass_dev(t, first ? n : ts, last ? n : ts);
+        const FftPassDev dev = pass_dev(t, first ? n : ts, last ? n : ts, blk);
         if (last) {
             LoadPlainT<false> ld{src};
             if (inverse)

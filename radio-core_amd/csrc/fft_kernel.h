@@ -356,9 +356,9 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
     const int64_t i0 = ti * W;
     const int wvalid = (int)((p.n_inner - i0) < W ? (p.n_inner - i0) : W);
     const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 +
-                            (p.in_t ? ti * p.in_t : i0 * p.in_i);
+                            (p.in_t ? (i0 >> 4) * p.in_t + (i0 & 15) : i0 * p.in_i);
     const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 +
-                             (p.out_t ? ti * p.out_t : i0 * p.out_i);
+                             (p.out_t ? (i0 >> 4) * p.out_t + (i0 & 15) : i0 * p.out_i);
     const int swz = p.load_along_l ? (W - 1) : 0;
 
     for (int e = tid; e < L; e += kThreads) {
@@ -637,11 +637,12 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
     // Lanes past the end of a row (last tile only) load line 0 of the tile again and are never stored:
     // every lane transforms its own line, so nothing has to be masked in between.
     const int wvalid = left < W ? left : W;
-    // (tile-blocked hand-over between strided passes: FftPass::in_t / out_t, 0 = the plain layout)
+    // (tile-blocked hand-over between strided passes: FftPass::in_t / out_t, 0 = the plain layout; the blocks are 16
+    // lines wide whatever W is: an 8-line tile is the lower or upper half of one)
     const int64_t in_base = (int64_t)id.batch * d.in_batch + id.o1 * p.in_o1 + id.o2 * p.in_o2 +
-                            (p.in_t ? (int64_t)bp.tile * p.in_t : (int64_t)i0 * p.in_i);
+                            (p.in_t ? (int64_t)(i0 >> 4) * p.in_t + (i0 & 15) : (int64_t)i0 * p.in_i);
     const int64_t out_base = (int64_t)id.batch * d.out_batch + id.o1 * p.out_o1 + id.o2 * p.out_o2 +
-                             (p.out_t ? (int64_t)bp.tile * p.out_t : (int64_t)i0);
+                             (p.out_t ? (int64_t)(i0 >> 4) * p.out_t + (i0 & 15) : (int64_t)i0);
     const unsigned in_l = (unsigned)p.in_l, in_i = (unsigned)p.in_i, out_k = (unsigned)p.out_k;
 
     // ---- global loads: all issued before anything waits -----------------------------------

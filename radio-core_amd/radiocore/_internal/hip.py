@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("RCFM_LIB") or os.path.join(os.path.dirname(_HERE), "_
 
 RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
 RCFM_OPT_LDS_CHAIN, RCFM_OPT_FUSED_TILES, RCFM_OPT_PHASE_LINK, RCFM_OPT_NARROW_TILES, RCFM_OPT_STATE_FENCE = 1, 2, 3, 4, 5   # rcfm_demod_set_option
-RCFM_OPT_PILOT_CHAIN, RCFM_OPT_DECIM_TILE, RCFM_OPT_LDS_DEEMPH, RCFM_OPT_PILOT_BLOCKED = 6, 7, 8, 9
+RCFM_OPT_PILOT_CHAIN, RCFM_OPT_DECIM_TILE, RCFM_OPT_LDS_DEEMPH, RCFM_OPT_PILOT_BLOCKED, RCFM_OPT_GRAPH = 6, 7, 8, 9, 10
 RCFM_TUNER_OPT_NARROW_TILES = 1                                                                                                # rcfm_tuner_set_option
 
 _ERR_SIZE, _ERR_INDEX, _ERR_RUNTIME, _ERR_ARG, _ERR_STATE = -1, -2, -3, -4, -5
@@ -313,18 +313,29 @@ class Arena:
             self._handle.value = None
 
 
+_binding = threading.local()     # what this thread has bound through `bound` (librcfm's binding is per thread too)
+
+
 class bound:
-    """`with bound(arena):` -- handles created by librcfm inside the block belong to `arena` (None: no-op)."""
+    """`with bound(arena):` -- tuner / demodulator handles created by librcfm inside the block belong to `arena`
+    (None: no-op).  Nests: leaving the block restores the binding the thread had when it entered."""
 
     def __init__(self, arena):
         self._arena = arena
+        self._prev = None
 
     def __enter__(self):
         if self._arena is not None:
+            self._prev = getattr(_binding, "arena", None)
             check(lib().rcfm_arena_bind(self._arena.value))
+            _binding.arena = self._arena
         return self
 
     def __exit__(self, *exc):
         if self._arena is not None:
-            check(lib().rcfm_arena_bind(None))
+            prev = self._prev
+            if prev is not None and not prev.value:      # closed in the meantime
+                prev = None
+            check(lib().rcfm_arena_bind(prev.value if prev is not None else None))
+            _binding.arena = prev
         return False

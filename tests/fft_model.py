@@ -86,6 +86,46 @@ def run_pass(p, n, src, dst):
                 dst[out_addr] = out
 
 
+def run_pass_in_place(p, n, buf):
+    """One strided pass reading and writing ONE array, tile after tile (what a kernel launched with in == out does, in the
+    most forgiving order: a tile is read completely before it is written)."""
+    run_pass_tiles = []
+    L = p.L
+    W = 16
+    radices = [p.radix[s] for s in range(p.nstages)]
+    for o1 in range(p.n_o1):
+        for o2 in range(p.n_o2):
+            for i0 in range(0, p.n_inner, W):
+                wv = min(W, p.n_inner - i0)
+                i = i0 + np.arange(wv)
+                lane = np.arange(wv)
+                tile_in = (i0 // W) * p.in_t + lane * p.in_i if p.in_t else i * p.in_i
+                tile_out = (i0 // W) * p.out_t + lane * p.out_i if p.out_t else i * p.out_i
+                l = np.arange(L)
+                in_addr = o1 * p.in_o1 + o2 * p.in_o2 + tile_in[None, :] + l[:, None] * p.in_l
+                out = lds_fft(buf[in_addr], radices)
+                if p.has_twiddle:
+                    line = o1 * p.tw_o1 + o2 * p.tw_o2 + i * p.tw_i
+                    out = out * np.exp(-2j * np.pi * (line[None, :] * l[:, None]) / n)
+                out_addr = o1 * p.out_o1 + o2 * p.out_o2 + tile_out[None, :] + l[:, None] * p.out_k
+                run_pass_tiles.append((np.sort(in_addr.ravel()), np.sort(out_addr.ravel())))
+                buf[out_addr] = out
+    return run_pass_tiles
+
+
+def model_fft_middle_in_place(x, plan):
+    """The routing FftEngine::c2c takes when in / out / tmp are not three distinct arrays: x -> tmp, the middle pass
+    tmp -> tmp IN PLACE, tmp -> out.  Returns (result, every tile of the middle pass wrote exactly what it read)."""
+    n = plan.n
+    assert plan.npass == 3
+    tmp = np.zeros(plan.tmp_stride, np.complex128)
+    out = np.zeros(n, np.complex128)
+    run_pass(plan.passes[0], n, np.asarray(x, np.complex128), tmp)
+    tiles = run_pass_in_place(plan.passes[1], n, tmp)
+    run_pass(plan.passes[2], n, tmp, out)
+    return out, all(np.array_equal(a, b) for a, b in tiles)
+
+
 def model_fft(x, plan):
     n = plan.n
     tmp = np.zeros(plan.tmp_stride, np.complex128)     # two-pass plans pad the scratch rows

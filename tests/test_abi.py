@@ -1,4 +1,4 @@
-"""CPU: librcfm.so loads and exports exactly what include/rcfm.h declares.
+"""CPU: librcfm.so loads and exports exactly what include/rcfm.h + include/rcfm_tools.h declare.
 
 No compute calls (this container has no GPU); the parity tests proper are the
 `-m gpu` ones, which go through this same ABI.
@@ -12,14 +12,19 @@ import pytest
 
 from conftest import ROOT
 
-HEADER = os.path.join(ROOT, "include", "rcfm.h")
+HEADER = os.path.join(ROOT, "include", "rcfm.h")                # what a host binds
+TOOLS_HEADER = os.path.join(ROOT, "include", "rcfm_tools.h")    # arenas, explicit FFT plans, kernel-form switches, profiling
 LIB = os.path.join(ROOT, "radio-core_amd", "radiocore", "_lib", "librcfm.so")
 
 
-def declared_functions():
-    text = open(HEADER).read()
+def declared_in(header):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rcfm_[a-z0-9_]+)\s*\(", text)))
+
+
+def declared_functions():
+    return sorted(set(declared_in(HEADER)) | set(declared_in(TOOLS_HEADER)))
 
 
 @pytest.fixture(scope="module")
@@ -39,6 +44,34 @@ def test_header_declares_the_expected_surface():
     assert len(names) >= 28
 
 
+def test_the_host_header_is_free_of_tooling():
+    """rcfm.h = the surface a host needs; what exists for this repo's tools and tests lives in rcfm_tools.h.  The two do
+    not overlap, the host header stands alone, and the tools header builds on it."""
+    host, tools = set(declared_in(HEADER)), set(declared_in(TOOLS_HEADER))
+    assert not host & tools
+    for name in host:
+        assert not name.startswith(("rcfm_arena_", "rcfm_profile_")), name
+    assert {"rcfm_fft_describe", "rcfm_fft_describe_plan", "rcfm_fft_c2c_plan", "rcfm_fft_c2c_rocfft",
+            "rcfm_tuner_set_option", "rcfm_demod_get_option", "rcfm_arena_create", "rcfm_profile_read"} <= tools
+    assert "rcfm_demod_set_option" in host          # RCFM_OPT_STATE_FENCE / _NARROW_TILES / _GRAPH are host options
+    assert '#include "rcfm.h"' in open(TOOLS_HEADER).read()
+    assert "rcfm_tools.h" not in re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    # the C host example binds the host header only
+    example = open(os.path.join(ROOT, "examples", "c_host.c")).read()
+    assert "rcfm_tools.h" not in example
+    example = re.sub(r"/\*.*?\*/", "", example, flags=re.S)
+    used = set(re.findall(r"\b(rcfm_[a-z0-9_]+)\s*\(", example))
+    assert used <= host, sorted(used - host)
+
+
+def test_every_symbol_the_library_exports_is_declared(lib):
+    """nm -D: the exported rcfm_* symbols are exactly the two headers' declarations (no undeclared back doors)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\bT (rcfm_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == declared_functions()
+
+
 def test_library_exports_every_declared_symbol(lib):
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
@@ -52,7 +85,7 @@ def test_binding_table_matches_header():
 
 def test_version_and_error_string(lib):
     lib.rcfm_version.restype = ctypes.c_int
-    assert lib.rcfm_version() == 101
+    assert lib.rcfm_version() == 102
     lib.rcfm_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.rcfm_last_error(), bytes)
 

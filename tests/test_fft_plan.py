@@ -83,3 +83,21 @@ def test_tile_blocked_hand_over_between_the_first_two_passes(lengths):
     assert fft_model.describe_plan(20 * 32 * 25, (20, 32, 25), blocked=1).passes[0].out_t == 0
     big = fft_model.describe(240_000_000)
     assert big.passes[0].out_t == 16 * 600 and big.passes[1].in_l == 640 * 600
+
+
+@pytest.mark.parametrize("lengths", [(20, 25, 32), (16, 16, 32), (64, 16, 16)])
+def test_a_blocked_middle_pass_may_not_run_in_place(lengths):
+    """Why FftEngine::c2c keeps the tile-blocked hand-over for calls with three distinct arrays (ADVICE r5, high): the
+    blocked second pass reads [tile][k_1][16] and writes the plain layout -- in place it overwrites inputs no tile has
+    read yet.  The plain plan of the same lengths reads and writes the same addresses per tile and is an FFT in place."""
+    n = lengths[0] * lengths[1] * lengths[2]
+    plain = fft_model.describe_plan(n, lengths, blocked=0)
+    blocked = fft_model.describe_plan(n, lengths, blocked=1)
+    r = np.random.default_rng(n)
+    x = r.standard_normal(n) + 1j * r.standard_normal(n)
+    want = np.fft.fft(x)
+    got, same_set = fft_model.model_fft_middle_in_place(x, plain)
+    assert same_set and np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+    got, same_set = fft_model.model_fft_middle_in_place(x, blocked)
+    assert not same_set
+    assert np.max(np.abs(got - want)) > 1e-3 * np.max(np.abs(want))     # garbage, as the advisor's simulation found

@@ -115,3 +115,102 @@ def test_window_storage_is_refused_where_the_window_wraps():
     hip.check(lib.rcfm_tuner_run(t, 0, 2, hip.ptr(out), hip.stream()))
     torch.cuda.synchronize()
     hip.check(lib.rcfm_tuner_destroy(t))
+
+
+def test_arena_counts_handles_not_pieces():
+    """A handle keeps its arena for life even when it holds no piece of it at the moment: a tuner of small buffers
+    only (everything below the 1 MiB arena threshold), and a tuner whose spectrum storage was attached (its own spectrum
+    piece dropped).  rcfm_arena_destroy refuses both (RCFM_ERR_STATE), as rcfm.h says."""
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    arena, small, big = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    hip.check(lib.rcfm_arena_create(ctypes.c_size_t(64 << 20), ctypes.byref(arena)))
+    hip.check(lib.rcfm_arena_bind(arena))
+    rolls = (ctypes.c_int64 * 1)(100)
+    bws = (ctypes.c_int32 * 1)(1000)
+    hip.check(lib.rcfm_tuner_create(20000, 1, rolls, bws, ctypes.byref(small)))        # 160 KB spectrum: hipMalloc
+    hip.check(lib.rcfm_arena_bind(None))
+    r, u, n = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    hip.check(lib.rcfm_arena_stats(arena, ctypes.byref(r), ctypes.byref(u), ctypes.byref(n)))
+    assert n.value == 0                                       # no piece ...
+    assert lib.rcfm_arena_destroy(arena) == -5, "a live handle without pieces must keep its arena alive"   # RCFM_ERR_STATE
+    assert b"still alive" in lib.rcfm_last_error()
+    hip.check(lib.rcfm_tuner_destroy(small))
+
+    hip.check(lib.rcfm_arena_bind(arena))
+    rolls = (ctypes.c_int64 * 2)(1000, -2000)
+    bws = (ctypes.c_int32 * 2)(60000, 60000)
+    hip.check(lib.rcfm_tuner_create(N, 2, rolls, bws, ctypes.byref(big)))
+    hip.check(lib.rcfm_arena_bind(None))
+    halo, nn = ctypes.c_int64(), ctypes.c_int64()
+    hip.check(lib.rcfm_tuner_spectrum_layout(big, ctypes.byref(halo), ctypes.byref(nn)))
+    ext = torch.zeros(nn.value + 2 * halo.value, dtype=torch.complex64, device="cuda")
+    hip.check(lib.rcfm_arena_stats(arena, None, None, ctypes.byref(n)))
+    pieces_before = n.value
+    hip.check(lib.rcfm_tuner_attach_spectrum(big, hip.ptr(ext), 0, 0))
+    hip.check(lib.rcfm_arena_stats(arena, None, None, ctypes.byref(n)))
+    assert n.value == pieces_before - 1                       # the spectrum piece went
+    assert lib.rcfm_arena_destroy(arena) == -5
+    x = torch.zeros(N, dtype=torch.complex64, device="cuda")
+    hip.check(lib.rcfm_tuner_load(big, hip.ptr(x), hip.stream()))     # still runs inside its (living) arena
+    torch.cuda.synchronize()
+    hip.check(lib.rcfm_tuner_destroy(big))
+    hip.check(lib.rcfm_arena_destroy(arena))
+    assert lib.rcfm_arena_bind(arena) != 0                    # a destroyed arena cannot be bound again
+
+
+def test_only_tuner_and_demodulator_handles_draw_from_a_bound_arena():
+    """Arena use is opt-in per handle: the function-static scratch of rcfm_fft_c2c, the plan cache of rcfm_hilbert and a
+    resampler handle created while an arena is bound all come from hipMalloc -- the arena stays empty and can go."""
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    arena = ctypes.c_void_p()
+    hip.check(lib.rcfm_arena_create(ctypes.c_size_t(32 << 20), ctypes.byref(arena)))
+    hip.check(lib.rcfm_arena_bind(arena))
+    n = 1 << 20                                                # 8 MiB scratch per transform
+    x = torch.randn(n, 2, device="cuda")
+    y = torch.empty_like(x)
+    hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(x), hip.ptr(y), hip.stream()))
+    lens = (ctypes.c_int64 * 3)(64, 128, 128)
+    hip.check(lib.rcfm_fft_c2c_plan(n, lens, 3, 1, 0, hip.ptr(x), hip.ptr(y), hip.stream()))
+    p = torch.randn(4, 240000, device="cuda")
+    z = torch.empty(4, 240000, 2, device="cuda")
+    hip.check(lib.rcfm_hilbert(4, 240000, hip.ptr(p), hip.ptr(z), hip.stream()))
+    rs = ctypes.c_void_p()
+    hip.check(lib.rcfm_resampler_create(8, 240000, 48000, 0, ctypes.byref(rs)))
+    hip.check(lib.rcfm_arena_bind(None))
+    torch.cuda.synchronize()
+    u, live = ctypes.c_size_t(), ctypes.c_size_t()
+    hip.check(lib.rcfm_arena_stats(arena, None, ctypes.byref(u), ctypes.byref(live)))
+    assert u.value == 0 and live.value == 0
+    hip.check(lib.rcfm_arena_destroy(arena))                  # ... while the resampler and the static buffers live on
+    q = torch.empty(8, 48000, device="cuda")
+    hip.check(lib.rcfm_resampler_run(rs, hip.ptr(torch.randn(8, 240000, device="cuda")), hip.ptr(q), hip.stream()))
+    hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(x), hip.ptr(y), hip.stream()))
+    torch.cuda.synchronize()
+    hip.check(lib.rcfm_resampler_destroy(rs))
+
+
+def test_nested_bindings_restore_the_outer_arena():
+    from radiocore._internal import hip
+    from radiocore.tools import Arena
+    lib = hip.lib()
+    outer, inner = Arena(8 << 20), Arena(8 << 20)
+    rolls = (ctypes.c_int64 * 1)(100)
+    bws = (ctypes.c_int32 * 1)(60000)
+    handles = []
+    with hip.bound(outer):
+        with hip.bound(inner):
+            t = ctypes.c_void_p()
+            hip.check(lib.rcfm_tuner_create(N, 1, rolls, bws, ctypes.byref(t)))
+            handles.append(t)
+        t = ctypes.c_void_p()
+        hip.check(lib.rcfm_tuner_create(N, 1, rolls, bws, ctypes.byref(t)))      # after the inner block: the OUTER arena again
+        handles.append(t)
+    assert inner.stats()["live_pieces"] >= 2 and outer.stats()["live_pieces"] >= 2
+    for t in handles:
+        hip.check(lib.rcfm_tuner_destroy(t))
+    inner.close()
+    outer.close()

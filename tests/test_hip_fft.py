@@ -1,6 +1,8 @@
 """GPU: the hand-written multi-pass FFT against numpy.fft (float32 tolerance) and
 against rocFFT on the lengths of the hot path."""
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -84,6 +86,39 @@ def test_engine_vs_rocfft_full_wideband(n):
     e_t = float(torch.sum(x.real.double() ** 2 + x.imag.double() ** 2))
     e_f = float(torch.sum(a.real.double() ** 2 + a.imag.double() ** 2)) / n
     assert abs(e_f - e_t) <= 1e-5 * e_t
+
+
+@pytest.mark.parametrize("n", [1 << 26, 240_000_000])
+def test_in_place_at_a_length_whose_plan_hands_over_tile_blocked(n):
+    """Three-pass plans beyond the Infinity Cache hand the first pass's output to the second one tile-blocked: the second
+    pass then reads another address set than it writes and may not run in place.  With in == out (rcfm.h allows it) the
+    engine runs the PLAIN layout of the same plan: same arithmetic, so the result equals the out-of-place one bit for
+    bit (round 5 ran the blocked pass in place here and returned wrong spectra)."""
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    plan = hip.FftPlan()
+    hip.check(lib.rcfm_fft_describe(n, 0, ctypes.byref(plan)))
+    assert plan.npass == 3 and plan.passes[0].out_t != 0 and plan.passes[1].in_t != 0, "not a blocked plan any more"
+    g = torch.Generator(device="cuda").manual_seed(n & 0xffff)
+    x = torch.view_as_complex(torch.randn(n, 2, generator=g, device="cuda"))
+    a = torch.empty_like(x)
+    hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(x), hip.ptr(a), hip.stream()))
+    b = x.clone()
+    hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(b), hip.ptr(b), hip.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+    # and both are the transform: Parseval + a few bins against a float64 sum over a slice-wise DFT
+    e_t = float(torch.sum(x.real.double() ** 2 + x.imag.double() ** 2))
+    e_f = float(torch.sum(a.real.double() ** 2 + a.imag.double() ** 2)) / n
+    assert abs(e_f - e_t) <= 1e-5 * e_t
+    t = torch.arange(n, device="cuda", dtype=torch.float64)
+    for k in (0, 1, 12345, n // 2 + 7, n - 1):
+        ph = -2.0 * np.pi * torch.remainder(t * k, n) / n
+        want = complex(float(torch.sum(x.real.double() * torch.cos(ph) - x.imag.double() * torch.sin(ph))),
+                       float(torch.sum(x.real.double() * torch.sin(ph) + x.imag.double() * torch.cos(ph))))
+        got = complex(a[k].item())
+        assert abs(got - want) <= 2e-5 * np.sqrt(e_t), (k, got, want)
 
 
 def test_engine_vs_rocfft_four_passes_at_a_billion_points():
