@@ -15,8 +15,13 @@ replicated, so total work is fixed as ranks grow: "scaling": "strong".
 `--gpus N` with N > 1 and no launcher around it starts its own N ranks
 (`python -m torch.distributed.run --nproc-per-node N`), one process per GPU; under
 a launcher (WORLD_SIZE set) the world must equal --gpus.  An N > 1 launch times
-BOTH partitionings of the wideband FFT back to back: replicated (the line's
-`value`) and the rotating owner (block `rotating`, or its `error`).
+BOTH partitionings of the wideband FFT back to back -- replicated, then the
+rotating owner -- and publishes the FASTER one whose gathered audio was verified
+as `value` (`config.parallelism` names it; the other keeps its own block,
+`rotating` or `replicated`; a failing second leg leaves the replicated line with
+the diagnosis in `rotating`).  Before them rank 0 times the same K steps alone
+(`n1`, `speedup_vs_n1`) and keeps one buffer's audio, which each partitioning
+must reproduce bit for bit (`self_check`).
 N = 1 allocates --placement-sets complete handle sets and reports the median
 one (`placement_spread` = fastest and slowest set).
 
@@ -56,6 +61,8 @@ CONFIGS = {
     # (tests/benchmark.py:85, WBFM(256e3, 32e3)) and a 200 kHz-channel band, batched like cfg4
     "geo256k": (240_000_000, 1024, 256_000, 32_000, 220_000, "WBFM"),
     "geo200k": (240_000_000, 1024, 200_000, 40_000, 200_000, "WBFM"),
+    # the reference's own single-station geometry (examples/receive_fm.py:18-19: 250 kHz -> 48 kHz), batched like cfg4
+    "geo250k": (240_000_000, 1024, 250_000, 48_000, 220_000, "WBFM"),
     # cfg5's band with MFM instead of FM: the LDS-resident chain plus the de-emphasis launches
     "nbmfm": (100_000_000, 8192, 12_500, 8_000, 12_000, "MFM"),
 }
@@ -322,6 +329,50 @@ def measure_lanes(lib, hip, x, rolls, bws, N, C, B, A, kind, steps, warmup, one_
                     "parity: tests/test_hip_lanes.py"}
 
 
+def measure_lane_pairs(lib, hip, x, sets, per_set_s, lo, mine, N, C, B, A, kind, steps, warmup):
+    """`pipelined` block of the headline: two lanes on the SAME handle sets the one-lane headline was timed on, pair by
+    pair -- set a's and set b's workspaces stay where they are, so `vs_one_lane` of a pair (its two-lane step time / the
+    mean of its two one-lane step times) carries no placement draw of its own.  The block reports the median pair."""
+    idx = list(range(len(sets)))
+    pairs = [(idx[i], idx[(i + 1) % len(idx)]) for i in range(len(idx))] if len(idx) > 2 else [(0, 1)]
+    rows = []
+    for a, b in pairs:
+        sa, sb = sets[a], sets[b]
+        # ONE de-emphasis state per channel, ordered across the two streams by the fence (radiocore.tools.Lanes)
+        hip.check(lib.rcfm_demod_bind_state(sb["demod"], sa["demod"], 0, 0, hip.stream()))
+        hip.check(lib.rcfm_demod_set_option(sa["demod"], 5, 1))          # RCFM_OPT_STATE_FENCE, after the binding
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+        def step(i):
+            hs, st = (sa, sb)[i % 2], ctypes.c_void_p(streams[i % 2].cuda_stream)
+            hip.check(lib.rcfm_tuner_load(hs["tuner"], hip.ptr(x), st))
+            hip.check(lib.rcfm_pipeline_run(hs["tuner"], hs["demod"], lo, mine, hip.ptr(hs["audios"][0]), st))
+
+        for i in range(warmup + 2):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        hip.check(lib.rcfm_demod_set_option(sa["demod"], 5, 0))
+        one = 0.5 * (per_set_s[a] + per_set_s[b])
+        rows.append({"sets": [a, b], "ms_per_step": round(dt * 1e3, 4), "one_lane_ms": round(one * 1e3, 4),
+                     "vs_one_lane": round(dt / one, 4)})
+    rows.sort(key=lambda r: r["vs_one_lane"])
+    mid = rows[len(rows) // 2]
+    dt = mid["ms_per_step"] * 1e-3
+    finite = all(bool(torch.isfinite(hs["audios"][0]).all()) for hs in sets)
+    return {"lanes": 2, "ms_per_step": mid["ms_per_step"], "value": round(N / dt / 1e6, 1), "unit": "Msamples/s",
+            "steps": steps, "path_hbm_frac": round(path_bytes(N, C, B, A, kind) / dt / HBM_PEAK, 4),
+            "vs_one_lane": mid["vs_one_lane"], "pairs": rows, "output_finite": finite,
+            "note": "consecutive buffers on alternating streams (radiocore.tools.Lanes / RCFM_OPT_STATE_FENCE) over PAIRS of "
+                    "the headline's own handle sets; per pair vs_one_lane = two-lane step / mean one-lane step of its two "
+                    "sets (same addresses); the block is the median pair; parity: tests/test_hip_lanes.py"}
+
+
 def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
     """One extra configuration on this GPU (cfg3 / cfg5; cfg4 is the headline): K timed steps of
     rcfm_tuner_load + rcfm_pipeline_run, input resident in HBM, same accounting as the headline."""
@@ -372,6 +423,76 @@ def measure_config(name, lib, hip, steps, warmup, chunk=0, with_surface=True):
                    "tests/test_hip_configs.py::test_run_all_narrowband_fm_geometry[MFM-12500-8000-0] (reduced band)" if name == "nbmfm" else
                    "tests/test_hip_configs.py::test_fused_chain_on_other_geometries[%s-%d-%d] (reduced band)" % (kind, B, A)),
     }
+
+
+PATH_MAP_B = (240_000, 250_000, 256_000)
+PATH_MAP_A = (32_000, 44_100, 48_000)
+
+
+def measure_path_map(lib, hip, steps=10, warmup=2, C=64, N=16_000_000):
+    """`other_configs.path_map`: where the cliffs are.  For B in {240 000, 250 000, 256 000} x A in {32 000, 44 100,
+    48 000} (the reference's example and benchmark shapes, examples/receive_fm.py:18-19, tests/benchmark.py:85, and CD
+    audio), 64 x WBFM behind a 16 MSPS tuner: which stages ran (librcfm's stage profile), which route that is, ms per
+    buffer.  A length with a prime factor above 5 (44 100 = 2^2 3^2 5^2 7^2) sends every transform of that length -- here
+    all of the demodulator's, which needs both B and A inside the engine -- to rocFFT."""
+    cells = {}
+    for B in PATH_MAP_B:
+        raster = N // (C + 2)
+        x, centres, f_in = synth_wideband_on_device(N, C, B, raster, "WBFM", lib, hip)
+        rolls = (ctypes.c_int64 * C)(*[int(f_in - f) for f in centres])
+        bws = (ctypes.c_int32 * C)(*([B] * C))
+        tuner = ctypes.c_void_p()
+        hip.check(lib.rcfm_tuner_create(N, C, rolls, bws, ctypes.byref(tuner)))
+        for A in PATH_MAP_A:
+            demod = ctypes.c_void_p()
+            hip.check(lib.rcfm_demod_create(2, C, B, A, 75e-6, 0, ctypes.byref(demod)))
+            audio = torch.empty((C, A, 2), dtype=torch.float32, device="cuda")
+
+            def step():
+                hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), hip.stream()))
+                hip.check(lib.rcfm_pipeline_run(tuner, demod, 0, C, hip.ptr(audio), hip.stream()))
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            lib.rcfm_profile_reset()
+            lib.rcfm_profile_enable(ctypes.c_uint64((1 << lib.rcfm_profile_stage_count()) - 1))
+            step()
+            torch.cuda.synchronize()
+            prof = read_profile(lib)
+            lib.rcfm_profile_enable(ctypes.c_uint64(0))
+            ran = {k: int(v[2]) for k, v in prof.items() if v[2] > 0}
+            chan_ms = sum(v[1] for k, v in prof.items() if k != "tuner_fft_N")
+            if "hilbert_mask" in ran:
+                route = "rocFFT for every demodulator transform (a length outside the engine)"
+            elif "ifft_A" in ran or "audio_spectrum" in ran:
+                route = "engine, pilot chain fused, decimation B -> A as separate transforms"
+            else:
+                route = "engine, fully fused (two-transform tiles + decimating tile)"
+            alg = C * (16.0 * B + 48.0 * B + 40.0 * A)
+            cells["%d->%d" % (B, A)] = {
+                "ms_per_step": round(dt * 1e3, 4), "channel_stages_ms": round(chan_ms, 4), "route": route,
+                "launches_per_step": int(sum(ran.values())), "stages_run": ran,
+                "channel_hbm_frac": round(alg / (chan_ms * 1e-3) / HBM_PEAK, 4) if chan_ms else None,
+                "output_finite": bool(torch.isfinite(audio).all())}
+            hip.check(lib.rcfm_demod_destroy(demod))
+            del audio
+        hip.check(lib.rcfm_tuner_destroy(tuner))
+        del x
+        torch.cuda.empty_cache()
+    ref = cells["240000->48000"]["channel_stages_ms"]
+    for c in cells.values():
+        c["channel_stages_vs_240000->48000"] = round(c["channel_stages_ms"] / ref, 3) if ref else None
+    return {"workload": "%d x WBFM behind a %d MSPS tuner, one buffer per step; channel_stages_ms = the step without the "
+                        "wideband FFT (HIP-event stage times); channel_hbm_frac on 64 B + 40 A algorithmic bytes per channel"
+                        % (C, N // 1_000_000),
+            "cells": cells,
+            "parity": "tests/test_hip_configs.py::test_path_map_cells_against_the_oracle[B-A] (reduced band, two buffers)"}
 
 
 def measure_cfg1_cpu(reps=5):
@@ -495,8 +616,9 @@ def parse_args():
                     help="N > 1: 'replicated' = every rank runs the whole wideband FFT and its own channels; 'rotating' = "
                          "rank i mod N owns buffer i (ingest + FFT) and sends each peer the spectrum bins its channels "
                          "read over xGMI (radiocore.tools.sharding.SpectrumRing); both gather the audio with RCCL.  "
-                         "'both' (default) times replicated (the line's `value`) and then rotating in the same launch "
-                         "(block `rotating`, or its `error`); at N = 1 there is nothing to partition")
+                         "'both' (default) times replicated and then rotating in the same launch and publishes the faster "
+                         "verified one as `value` (the other in its own block; `rotating.error` if the second leg fails); "
+                         "at N = 1 there is nothing to partition")
     ap.add_argument("--placement-sets", type=int, default=4,
                     help="N = 1: complete handle sets (tuner + demodulator + audio block) allocated side by side; each is "
                          "timed over exactly K steps, `value` is the MEDIAN set and `placement_spread` the fastest and "
@@ -508,6 +630,10 @@ def parse_args():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="rcfm_demod_set_option on every demodulator handle of the timed legs (A/B runs: tools/ab_args.sh): "
                          + ", ".join(sorted(DEMOD_OPTIONS)))
+    ap.add_argument("--self-check", action="store_true", help=argparse.SUPPRESS)     # the default for N > 1
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="N > 1: skip the one-rank leg on rank 0 (`n1`, `speedup_vs_n1`) and the bit-for-bit comparison of "
+                         "one buffer through each partitioning with the single-GPU audio (`self_check`)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other GPU configurations (cfg3, cfg5, batched cfg2) reported beside the headline")
     ap.add_argument("--profile-all", action="store_true", help="print the per-stage table to stderr as well")
@@ -575,6 +701,8 @@ class Run:
         self.limit = float(os.environ.get("RCFM_BENCH_TIMEOUT", "300"))
         # the line of the legs that have finished: a later leg that fails still publishes them (rank 0)
         self.finished = None
+        # --self-check (default for N > 1): the one-rank leg + the bit-for-bit comparison of both partitionings with it
+        self.self_check = self.multi and not args.no_self_check
 
     def progress(self, name, step=-1):
         self.phase.update(name=name, step=step, t=time.monotonic())
@@ -664,7 +792,7 @@ def stage_table(prof, N, B, A, kind, channels, steps=1):
     return out
 
 
-def measure_partitioning(run, x, centres, f_in, parallelism, primary):
+def measure_partitioning(run, x, centres, f_in, parallelism, primary, ref=None):
     """One leg: K timed steps of the hot path under one partitioning of the work over the ranks.  `primary`: the leg
     the line's `value` comes from (N = 1: also cpu_baseline, parity spot check)."""
     args, rank, world, multi, backend = run.args, run.rank, run.world, run.multi, run.backend
@@ -817,6 +945,12 @@ def measure_partitioning(run, x, centres, f_in, parallelism, primary):
     if nsets > 1:                                 # the decomposition of the set the value comes from
         prof_all = profile_pass(1)
 
+    lanes_block = None
+    if primary and not multi and nsets >= 2 and not args.no_extras:
+        progress("two lanes over pairs of the handle sets")
+        lanes_block = measure_lane_pairs(lib, hip, x, sets, [t[0] / args.steps for t in timed], lo, mine, N, C, B, A, kind,
+                                         args.steps, args.warmup)
+
     per_rank = None
     if multi:
         progress("max over ranks")
@@ -915,6 +1049,8 @@ def measure_partitioning(run, x, centres, f_in, parallelism, primary):
             "note": "%d complete handle sets side by side, each timed over exactly %d steps between barriers; `value` / "
                     "`ms_per_step` / `roofline` / `stages` are the set with the median time (upper median of an even "
                     "count)" % (nsets, args.steps)}
+    if lanes_block is not None:
+        result["pipelined"] = lanes_block
     if multi:
         result["rccl_ranks"] = run.rccl_ranks
 
@@ -959,6 +1095,28 @@ def measure_partitioning(run, x, centres, f_in, parallelism, primary):
                 "blocks": int(sum(1 for a, b in bounds if b > a)),
                 "own_block_equal": bool(torch.equal(g[lo:hi], cur["set"]["audios"][(counter[0] - 1) % nbuf])),
             }
+
+    if multi and run.self_check:
+        # One buffer from first-buffer state through this partitioning, gathered, against the one-rank audio rank 0
+        # computed in this launch (measure_one_rank): bit for bit -- sharding only changes WHO computes a channel.
+        progress("self check")
+        if rotating:
+            surf.reset_states()
+        else:
+            hip.check(lib.rcfm_demod_reset_state(cur["set"]["demod"], hip.stream()))
+        step()
+        barrier()
+        if rank == 0:
+            g = gathereds[(counter[0] - 1) % nbuf]
+            if ref is None:
+                result["self_check"] = {"bit_identical": False, "error": "no one-rank reference in this launch"}
+            else:
+                same = bool(torch.equal(g, ref))
+                peak = float(ref.abs().amax().item())
+                result["self_check"] = {
+                    "bit_identical": same, "max_abs_diff": 0.0 if same else float((g - ref).abs().amax().item()),
+                    "peak": peak, "channels": C,
+                    "against": "one buffer from first-buffer state on ONE GPU (rank 0, same launch), all %d channels" % C}
 
     if not args.no_pcie:
         # Host-fed variant (DESIGN.md sections 4, 5): the wideband buffer starts in page-locked host memory
@@ -1055,8 +1213,94 @@ def measure_partitioning(run, x, centres, f_in, parallelism, primary):
     return result, (roll_a, bw_a)
 
 
+def measure_one_rank(run, x, centres, f_in):
+    """N > 1 launches only, rank 0, before any data-path collective: the SAME K steps on ONE GPU (all channels, one
+    handle set) -- the denominator of `speedup_vs_n1` measured in the same launch on the same box -- and the audio of
+    one buffer from first-buffer state, which both partitionings must reproduce bit for bit (`self_check`).  Two
+    references: the handle's default wideband plan (what the replicated partitioning runs) and the default ORDER of the
+    plan (RCFM_TUNER_OPT_ALIGNED_PLAN = 0: what a rotating owner runs, whose spectrum lives in an attached slot)."""
+    args = run.args
+    from radiocore._internal import hip
+    lib = hip.lib()
+    N, C, B, A, raster, kind = CONFIGS[args.config]
+    ch = 2 if kind == "WBFM" else 1
+    rolls = (ctypes.c_int64 * C)(*[int(f_in - f) for f in centres])
+    bws = (ctypes.c_int32 * C)(*([B] * C))
+    tuner, demod = ctypes.c_void_p(), ctypes.c_void_p()
+    hip.check(lib.rcfm_tuner_create(N, C, rolls, bws, ctypes.byref(tuner)))
+    hip.check(lib.rcfm_tuner_shard(tuner, 0, C))
+    hip.check(lib.rcfm_demod_create({"FM": 0, "MFM": 1, "WBFM": 2}[kind], C, B, A, 75e-6, args.chunk, ctypes.byref(demod)))
+    apply_options(lib, hip, demod, args.opt)
+    audio = torch.empty((C, A, ch), dtype=torch.float32, device="cuda")
+
+    def step():
+        hip.check(lib.rcfm_tuner_load(tuner, hip.ptr(x), hip.stream()))
+        hip.check(lib.rcfm_pipeline_run(tuner, demod, 0, C, hip.ptr(audio), hip.stream()))
+
+    for k in range(args.warmup):
+        run.progress("one-rank leg: warm-up", k)
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        run.progress("one-rank leg: timed step", k)
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    refs = {}
+    for name, aligned in (("replicated", 1), ("rotating", 0)):
+        hip.check(lib.rcfm_tuner_set_option(tuner, hip.RCFM_TUNER_OPT_ALIGNED_PLAN, aligned))
+        hip.check(lib.rcfm_demod_reset_state(demod, hip.stream()))
+        step()
+        torch.cuda.synchronize()
+        refs[name] = audio.clone()
+    hip.check(lib.rcfm_demod_destroy(demod))
+    hip.check(lib.rcfm_tuner_destroy(tuner))
+    del audio
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 4), "value": round(N / dt / 1e6, 2), "unit": "Msamples/s", "steps": args.steps,
+            "note": "rank 0 alone, all %d channels, one handle set, timed in this launch before the first data-path "
+                    "collective (the other ranks wait at a barrier)" % C}, refs
+
+
+def partitioning_verified(r):
+    """A leg's number may become `value` only when its gathered audio was checked: every rank's block arrived with audio
+    in it, rank 0's own block is the one it computed, and (when the launch had a one-rank reference) one buffer from
+    first-buffer state equals the single-GPU audio bit for bit."""
+    g, sc = r.get("gather_check"), r.get("self_check")
+    ok = bool(g) and g["finite"] and g["own_block_equal"] and g["blocks_with_audio"] == g["blocks"]
+    return ok and (sc is None or sc["bit_identical"])
+
+
+def publish_faster(first, second, n1):
+    """Both partitionings ran in one launch: the line's `value` is the FASTER one whose audio was verified
+    (config.parallelism names it); the other one keeps its own block."""
+    legs = {"replicated": first, "rotating": second}
+    ok = {k: partitioning_verified(v) for k, v in legs.items()}
+    order = sorted(legs, key=lambda k: -legs[k]["value"])
+    winner = next((k for k in order if ok[k]), "replicated")
+    loser = "rotating" if winner == "replicated" else "replicated"
+    line = dict(legs[winner])
+    for k in ("rotating", "replicated"):
+        line.pop(k, None)
+    block = {k: legs[loser][k] for k in ROTATING_KEYS if k in legs[loser]}
+    block["parallelism"] = legs[loser]["config"]["parallelism"]
+    block["vs_published"] = round(legs[loser]["value"] / line["value"], 4) if line["value"] else None
+    line[loser] = block
+    # what the first leg carried for the whole launch stays with the line
+    for k in ("cpu_baseline", "rccl_ranks", "kernel_source_sha", "n1"):
+        if k in first:
+            line[k] = first[k]
+    line["speedup_vs_n1"] = round(line["value"] / n1["value"], 4) if n1 and n1["value"] else None
+    line["partitionings"] = {
+        "published": winner, "verified": ok, "value": {k: legs[k]["value"] for k in legs},
+        "rule": "the faster partitioning whose gather_check (and self_check, when present) passed; replicated when "
+                "neither did"}
+    return line
+
+
 ROTATING_KEYS = ("value", "unit", "ms_per_step", "steps", "path_hbm_frac", "amdahl_bound_speedup", "per_rank",
-                 "rotating_owner", "channel_stage_value", "gather_check", "pcie_inclusive", "stages", "roofline")
+                 "rotating_owner", "channel_stage_value", "gather_check", "self_check", "pcie_inclusive", "stages", "roofline")
 
 
 def main():
@@ -1085,9 +1329,21 @@ def main():
 
     legs = ["replicated", "rotating"] if (args.parallelism == "both" and run.world > 1) else \
            ["replicated" if args.parallelism == "both" else args.parallelism]
+    n1, refs = None, {}
+    if run.self_check:
+        # every rank is up (start_group ran a collective); rank 0 now works alone, the others wait for it
+        run.phase["leg"] = "one-rank leg"
+        if run.rank == 0:
+            n1, refs = measure_one_rank(run, x, centres, f_in)
+        run.progress("barrier after the one-rank leg")
+        run.dist.barrier()
     run.phase["leg"] = legs[0]
-    result, (roll_a, bw_a) = measure_partitioning(run, x, centres, f_in, legs[0], primary=True)
+    result, (roll_a, bw_a) = measure_partitioning(run, x, centres, f_in, legs[0], primary=True, ref=refs.get(legs[0]))
     rank, world, multi = run.rank, run.world, run.multi
+    if multi and rank == 0:
+        # against ONE GPU in the same launch (null when the one-rank leg was skipped)
+        result["n1"] = n1
+        result["speedup_vs_n1"] = round(result["value"] / n1["value"], 4) if n1 and n1["value"] else None
     if len(legs) > 1:
         # the second partitioning in the same launch: its own watchdog budget, its failure is a block of the line
         run.finished = result
@@ -1097,23 +1353,23 @@ def main():
         try:
             if os.environ.get("RCFM_BENCH_FAIL_ROTATING") == "1" and run.rank == 1:      # tests/test_bench_multirank.py
                 raise RuntimeError("injected failure of the rotating leg")
-            second, _ = measure_partitioning(run, x, centres, f_in, "rotating", primary=False)
-            block = {k: second[k] for k in ROTATING_KEYS if k in second}
-            block["parallelism"] = second["config"]["parallelism"]
-            block["vs_replicated"] = round(second["value"] / result["value"], 4) if result["value"] else None
-            result["rotating"] = block
+            second, _ = measure_partitioning(run, x, centres, f_in, "rotating", primary=False, ref=refs.get("rotating"))
+            if rank == 0:
+                result = publish_faster(result, second, n1)
         except Exception as e:
             # the peers are somewhere inside the leg's collectives: no way to tell them -- publish and leave
             run.fail("rotating leg raised %s: %s" % (type(e).__name__, str(e)[:300]))
         run.finished = None
         run.phase["leg"] = "done"
 
+    del refs
     ms_per_step = result["ms_per_step"]
     if rank == 0 and world == 1 and args.config == "cfg4" and not args.no_extras and not multi:
         # the other GPU configurations of BASELINE.json on the same box, outside the headline's timed region
         run.progress("other configurations")
-        result["pipelined"] = measure_lanes(lib, hip, x, roll_a, bw_a, N, C, B, A, kind, args.steps, args.warmup,
-                                            ms_per_step * 1e-3)
+        if "pipelined" not in result:      # (--placement-sets 1: no pair of sets to run lanes on)
+            result["pipelined"] = measure_lanes(lib, hip, x, roll_a, bw_a, N, C, B, A, kind, args.steps, args.warmup,
+                                                ms_per_step * 1e-3)
         surface4 = measure_surface("cfg4", x, centres, args.steps, args.warmup, ms_per_step * 1e-3)
         del x
         torch.cuda.empty_cache()
@@ -1123,6 +1379,8 @@ def main():
             "cfg2_batched": measure_batched_cfg2(lib, hip, 10, 2),
             "geo256k": measure_config("geo256k", lib, hip, 10, 2, with_surface=False),
             "geo200k": measure_config("geo200k", lib, hip, 10, 2, with_surface=False),
+            "geo250k": measure_config("geo250k", lib, hip, 10, 2, with_surface=False),
+            "path_map": measure_path_map(lib, hip),
             "nbmfm": measure_config("nbmfm", lib, hip, 10, 2, with_surface=False),
             "cfg2_single": measure_cfg2_single(),
             "cfg1_cpu": measure_cfg1_cpu(),

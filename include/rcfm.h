@@ -175,10 +175,11 @@ int rcfm_demod_bind_state(rcfm_demod_t single, rcfm_demod_t batched, int index, 
  *                         from buffer i (deemphasis.py:64): with the fence on, every launch sequence that touches the
  *                         shared state waits for the event the previous one recorded, on whichever stream that was.
  *                         Set it on any ONE handle of the sharing group, after the binding
- *   RCFM_OPT_GRAPH        (default 1) a handle of ONE channel (the reference's per-channel call, fm.py:46 / mfm.py:51 /
+ *   RCFM_OPT_GRAPH        (default 0) a handle of ONE channel (the reference's per-channel call, fm.py:46 / mfm.py:51 /
  *                         wbfm.py:66; tests/benchmark.py:29-31 times exactly these) replays its launch chain from a
  *                         captured hipGraph when the call's pointers and stream kind repeat: one graph launch instead of
- *                         ten kernel launches.  0: plain launches.  Results are bit-identical either way */
+ *                         ten kernel launches.  0: plain launches.  Results are bit-identical either way.  Off by default: on ROCm 7 the
+ *                         graph launch costs as much as the launches it replaces (profiles/r06_a_single_call.txt) */
 enum { RCFM_OPT_NARROW_TILES = 4, RCFM_OPT_STATE_FENCE = 5, RCFM_OPT_GRAPH = 10 };
 int rcfm_demod_set_option(rcfm_demod_t d, int option, int value);
 int rcfm_demod_destroy(rcfm_demod_t d);

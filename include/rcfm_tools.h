@@ -44,7 +44,13 @@ int rcfm_arena_destroy(rcfm_arena_t arena);
 
 /* Which tile width rcfm_tuner_run uses (rcfm_pipeline_run passes the demodulator's RCFM_OPT_NARROW_TILES instead):
  * 0 = always 16 lines per tile, 1 (default) = 8 when a launch has fewer than two 16-line tiles per CU, 2 = always 8. */
-enum { RCFM_TUNER_OPT_NARROW_TILES = 1 };
+enum { RCFM_TUNER_OPT_NARROW_TILES = 1,
+       /* 1 (default): a wideband FFT whose default plan's last pass stores segments that straddle 128-byte lines
+        * (N = 2.4e8 = 600 x 625 x 640: output stride 375 000 bins = 64 mod 128 bytes) runs the aligned order of the same
+        * pass lengths in the padded-rows layout instead (640 x 625 x 600, rcfm_fft_describe_plan layout 2) -- while the
+        * handle uses its own spectrum storage (an attached one has no room for the padded intermediate); 0: always the
+        * default plan.  Takes effect with the next rcfm_tuner_load; same spectrum within float32 rounding. */
+       RCFM_TUNER_OPT_ALIGNED_PLAN = 2 };
 int rcfm_tuner_set_option(rcfm_tuner_t t, int option, int value);
 
 /* Which forms of the chain a handle may use (no reference counterpart: the reference has one form of everything).
@@ -87,6 +93,8 @@ typedef struct rcfm_fft_pass {
     int32_t has_twiddle, load_along_l;
     int64_t in_t, out_t; /* tile-blocked hand-over between strided passes: element offset of tile t (16 lines) = t * in_t /
                             t * out_t; 0 = the plain layout (16 * in_i, 16) */
+    int32_t flat_outer;  /* 1: the launch walks (o1, o2, tile) as one flat, XCD-aware tile index (layout 2's first pass) */
+    int32_t reserved_;
 } rcfm_fft_pass;
 typedef struct rcfm_fft_plan {
     int64_t n;
@@ -95,15 +103,18 @@ typedef struct rcfm_fft_plan {
     rcfm_fft_pass pass[4];
 } rcfm_fft_plan;
 int rcfm_fft_describe(int64_t n, int max_l /* 0 = default cap on a pass length */, rcfm_fft_plan* plan);
-/* The plan for given pass lengths (what rcfm_fft_c2c_plan runs).  blocked: the tile-blocked hand-over between the first two
- * passes of a three-pass plan: -1 = as the engine decides (transforms beyond the Infinity Cache), 0 = never, 1 = whenever
- * the lengths allow it (tests/test_fft_plan.py models it at small n). */
-int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int blocked, rcfm_fft_plan* plan);
+/* The plan for given pass lengths (what rcfm_fft_c2c_plan runs).  layout of the intermediate arrays of a three-pass plan:
+ *   -1 = as the engine decides (tile-blocked hand-over between the first two passes for transforms beyond the Infinity
+ *        Cache, else plain), 0 = plain, 1 = tile-blocked whenever the lengths allow it (tests/test_fft_plan.py models it
+ *        at small n), 2 = padded rows: scratch rows of n_3 points at a pitch of whole 128-byte lines -- tmp_stride > n, a
+ *        private layout; with it an order of the pass lengths whose LAST pass stores aligned segments keeps every other
+ *        write aligned as well (N = 2.4e8 as 640 x 625 x 600, what rcfm_tuner_load runs: RCFM_TUNER_OPT_ALIGNED_PLAN). */
+int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int layout, rcfm_fft_plan* plan);
 /* The same transform with the pass lengths given by the caller (their product is n, each within the engine's tile
  * lengths; RCFM_ERR_ARG otherwise): plan sweeps (tools/plan_sweep.py) and tests that put a tile length into a role the
  * planner does not use it in (tests/test_hip_fft.py). */
-int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int batch, int inverse, const void* in,
-                      void* out, void* stream);
+int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int layout, int batch, int inverse,
+                      const void* in, void* out, void* stream);
 /* The same transform through rocFFT (any n): the A/B partner of rcfm_fft_c2c in
  * tools/bench_fft.py and the fallback for lengths the engine refuses. */
 int rcfm_fft_c2c_rocfft(int64_t n, int batch, int inverse, const void* in, void* out, void* stream);

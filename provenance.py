@@ -1,7 +1,7 @@
 """Ties measured evidence to the code it describes.
 
 `kernel_source_sha()` is a digest of everything that defines the device code of librcfm.so (the HIP sources and
-headers under radio-core_amd/csrc plus include/rcfm.h).  tools/traffic_summary.py stamps it (and the commit) into
+headers under radio-core_amd/csrc plus include/rcfm.h and rcfm_tools.h).  tools/traffic_summary.py stamps it (and the commit) into
 profiles/hbm_traffic.json when the PMC passes are summarised; bench.py recomputes it at run time and reports
 `"traffic": null, "traffic_stale": true` when the kernels have changed since the counters were collected.
 """
@@ -18,6 +18,7 @@ def kernel_source_files(root=ROOT):
     csrc = os.path.join(root, "radio-core_amd", "csrc")
     files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip"))]
     files.append(os.path.join(root, "include", "rcfm.h"))
+    files.append(os.path.join(root, "include", "rcfm_tools.h"))
     return files
 
 

@@ -340,6 +340,8 @@ using namespace rcfm;
 // Tile width (RCFM_OPT_NARROW_TILES / RCFM_TUNER_OPT_NARROW_TILES, per handle): 0 = every tile kernel with 16 lines per
 // tile, 1 (default) = 8 lines when a launch would leave most CUs without a tile, 2 = always 8.
 constexpr int kNarrowDefault = 1;
+// RCFM_TUNER_OPT_ALIGNED_PLAN (rcfm_tools.h): 1 = run the aligned order of a wideband plan whose last pass straddles lines.
+constexpr int kAlignedPlanDefault = 1;
 // One tile per CU and a half-empty chip: that is where a launch lasts one tile's latency and narrower tiles (twice as
 // many, half the threads each) shorten it.  From two 16-line tiles per CU on, the wide ones stream better.
 static bool narrow_launch(const FftEngine& e, int signals, int mode) {
@@ -384,6 +386,20 @@ struct rcfm_tuner_s {
     std::unique_ptr<FftPlan> forward;          // rocFFT fallback for lengths outside the engine
     std::unique_ptr<FftEngine> forward_engine;
     DeviceBuffer forward_tmp;                  // engine: the last pass cannot run in place
+    // RCFM_TUNER_OPT_ALIGNED_PLAN: the default plan's pass lengths in the order whose LAST pass stores aligned segments,
+    // in the padded-rows layout (fft_engine.h, layout 2) -- N = 2.4e8 = 640 x 625 x 600 with 608-point scratch rows.  Its
+    // first intermediate lives in the handle's own spectrum storage (sized for it), so an attached storage runs the
+    // default plan.  bin_window() -- the protocol between ranks -- always speaks in rows of the default plan.
+    std::unique_ptr<FftEngine> forward_aligned;
+    int opt_aligned = kAlignedPlanDefault;
+    FftRowWindow window_aligned{0, 0};
+    bool windowed_aligned = false;
+    size_t own_spectrum_bytes() const {
+        int64_t elems = n + 2 * halo;
+        if (forward_aligned) elems = std::max<int64_t>(elems, forward_aligned->tmp_stride());
+        return sizeof(float2) * (size_t)elems;
+    }
+    bool use_aligned() const { return forward_aligned && opt_aligned && ext == nullptr && X.bytes() >= own_spectrum_bytes(); }
     DeviceBuffer band_tmp;
     bool loaded = false;
     // rcfm_tuner_shard: rows of the spectrum (FftRowWindow) the declared channel range reads
@@ -398,9 +414,10 @@ struct rcfm_tuner_s {
     // Rows of the spectrum (row = n_1 consecutive bins, n_1 = the forward plan's first pass length) that channels
     // [first, first + count) read, as a circular window lo..hi: everything but the longest run of unused rows.
     // false: no engine, too few rows, or nothing worth skipping -- the range reads (nearly) the whole spectrum.
-    bool row_window(int first, int count, FftRowWindow* w) const {
-        if (!forward_engine || count == 0) return false;
-        const int64_t f0 = forward_engine->row_length();
+    bool row_window(int first, int count, FftRowWindow* w, const FftEngine* eng = nullptr) const {
+        if (!eng) eng = forward_engine.get();
+        if (!eng || count == 0) return false;
+        const int64_t f0 = eng->row_length();
         const int64_t rows = n / f0;
         if (rows < 64) return false;
         std::vector<char> used((size_t)rows, 0);
@@ -433,6 +450,7 @@ struct rcfm_tuner_s {
         shard_first = first;
         shard_count = count;
         windowed = row_window(first, count, &window);
+        windowed_aligned = forward_aligned && row_window(first, count, &window_aligned, forward_aligned.get());
     }
 
     // The same window in bins: [first_bin, first_bin + nbins) modulo n (nbins = n: everything).
@@ -633,7 +651,10 @@ struct rcfm_demod_s {
     // into a hipGraph (the first one has warmed up every lazily built table and workspace, so the capture allocates
     // nothing); later calls replay it with ONE graph launch on the caller's stream.  Same kernels, same arguments:
     // bit-identical.  Not used while a stage timer or the state fence (events on the stream) is on.
-    bool opt_graph = true;
+    // OFF by default: measured on MI355X / ROCm 7 (profiles/r06_a_single_call.txt) a graph launch of the ten-kernel WBFM
+    // chain costs what the ten stream launches cost (73.4 vs 74.8 us synchronous, 61.0 vs 57.8 us queued), and the
+    // shorter MFM / FM chains lose 4 - 6 us per call: this runtime's graph launch is no cheaper than its kernel launches.
+    bool opt_graph = false;
     struct GraphSlot {
         const void* iq;
         void* audio;
@@ -1343,12 +1364,19 @@ int rcfm_tuner_create(int64_t n, int nch, const int64_t* roll_host, const int32_
             for (int i = 0; i < nch; ++i) base[i] = (int32_t)((n - t->roll[i]) % n);
             t->base_dev.upload(base.data(), sizeof(int32_t) * nch);
         }
-        t->X.reset(sizeof(float2) * (size_t)(n + 2 * t->halo));
         FftPlanDesc probe;
         if (use_engine() && fft_plan_describe(n, &probe)) {
             t->forward_engine = std::make_unique<FftEngine>(n);
-            t->forward_tmp.reset(sizeof(float2) * (size_t)t->forward_engine->tmp_stride());
-        } else {
+            int64_t tmp_elems = t->forward_engine->tmp_stride();
+            int64_t order[3];
+            if (fft_plan_aligned_order(t->forward_engine->desc(), order)) {
+                t->forward_aligned = std::make_unique<FftEngine>(n, order, 3, 2);
+                tmp_elems = std::max(tmp_elems, t->forward_aligned->tmp_stride());
+            }
+            t->forward_tmp.reset(sizeof(float2) * (size_t)tmp_elems);
+        }
+        t->X.reset(t->own_spectrum_bytes());
+        if (!t->forward_engine) {
             t->forward = std::make_unique<FftPlan>(FftKind::C2C_FORWARD, (size_t)n, 1, false);
             t->forward_work.reserve(t->forward->work_bytes());
         }
@@ -1367,12 +1395,15 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
             bool halo_done = false;
             if (t->forward_engine) {
                 // the last pass writes the halos itself (bins near both ends are stored twice): no copy launches
-                FftRowWindow w = t->windowed ? t->window
-                                             : FftRowWindow{0, (int)(t->n / t->forward_engine->row_length()) - 1, 0};
+                const bool al = t->use_aligned();
+                const FftEngine& eng = al ? *t->forward_aligned : *t->forward_engine;
+                FftRowWindow w = al ? (t->windowed_aligned ? t->window_aligned : FftRowWindow{0, (int)(t->n / eng.row_length()) - 1, 0})
+                                    : (t->windowed ? t->window : FftRowWindow{0, (int)(t->n / eng.row_length()) - 1, 0});
                 w.halo = (int)t->halo;
                 halo_done = t->halo > 0;
-                t->forward_engine->c2c(static_cast<const float2*>(x), t->spectrum(), t->forward_tmp.as<float2>(),
-                                       1, false, 1.0f, as_stream(stream), &w);
+                // (aligned plan: x -> the spectrum storage as scratch -> forward_tmp -> the spectrum, no pass in place)
+                eng.c2c(static_cast<const float2*>(x), t->spectrum(), t->forward_tmp.as<float2>(), 1, false, 1.0f,
+                        as_stream(stream), &w, al ? t->X.as<float2>() : nullptr);
             } else {
                 t->forward_work.reserve(t->forward->work_bytes());
                 t->forward->exec(const_cast<void*>(x), t->spectrum(), t->forward_work.get(), as_stream(stream));
@@ -1385,7 +1416,7 @@ int rcfm_tuner_load(rcfm_tuner_t t, const void* x, void* stream) {
             }
         }
         t->loaded = true;
-        t->loaded_windowed = t->forward_engine && t->windowed;
+        t->loaded_windowed = t->forward_engine && (t->use_aligned() ? t->windowed_aligned : t->windowed);
         t->loaded_first = t->shard_first;
         t->loaded_count = t->shard_count;
     });
@@ -1431,7 +1462,7 @@ int rcfm_tuner_attach_spectrum(rcfm_tuner_t t, void* storage, int loaded_first, 
         t->ext = static_cast<float2*>(storage);
         t->ext_window = false;
         // the handle's own [halo | n | halo] buffer is not needed while the caller supplies the storage
-        const size_t own_bytes = sizeof(float2) * (size_t)(t->n + 2 * t->halo);
+        const size_t own_bytes = t->own_spectrum_bytes();
         if (storage != nullptr) t->X.reset(0);
         else if (t->X.bytes() < own_bytes) t->X.reset(own_bytes);
         // what the storage holds: the bins of channels [loaded_first, loaded_first + loaded_count), or nothing yet
@@ -1484,6 +1515,7 @@ int rcfm_tuner_set_option(rcfm_tuner_t t, int option, int value) {
                 RC_REQUIRE(value >= 0 && value <= 2, RCFM_ERR_ARG, "narrow tiles: 0 never, 1 automatic, 2 always");
                 t->opt_narrow = value;
                 break;
+            case RCFM_TUNER_OPT_ALIGNED_PLAN: t->opt_aligned = value != 0; break;
             default: RC_REQUIRE(false, RCFM_ERR_ARG, "unknown tuner option");
         }
     });
@@ -2222,11 +2254,12 @@ int rcfm_fft_describe(int64_t n, int max_l, rcfm_fft_plan* plan) {
     });
 }
 
-int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int blocked, rcfm_fft_plan* plan) {
+int rcfm_fft_describe_plan(int64_t n, const int64_t* pass_lengths, int npass, int layout, rcfm_fft_plan* plan) {
     return guarded([&] {
         RC_REQUIRE(plan != nullptr && pass_lengths != nullptr, RCFM_ERR_ARG, "NULL argument");
+        RC_REQUIRE(layout >= -1 && layout <= 2, RCFM_ERR_ARG, "layout: -1 automatic, 0 plain, 1 tile-blocked, 2 padded rows");
         FftPlanDesc d;
-        RC_REQUIRE(fft_plan_describe(n, &d, 0, pass_lengths, npass, blocked), RCFM_ERR_ARG,
+        RC_REQUIRE(fft_plan_describe(n, &d, 0, pass_lengths, npass, layout), RCFM_ERR_ARG,
                    "pass lengths not supported by the FFT engine");
         std::memcpy(plan, &d, sizeof(d));
     });
@@ -2247,21 +2280,28 @@ int rcfm_fft_c2c(int64_t n, int batch, int inverse, const void* in, void* out, v
     });
 }
 
-int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int batch, int inverse, const void* in, void* out,
-                      void* stream) {
+int rcfm_fft_c2c_plan(int64_t n, const int64_t* pass_lengths, int npass, int layout, int batch, int inverse, const void* in,
+                      void* out, void* stream) {
     return guarded([&] {
         RC_REQUIRE(in && out && batch >= 1 && pass_lengths && npass >= 1 && npass <= kFftMaxPasses, RCFM_ERR_ARG, "bad argument");
+        RC_REQUIRE(layout >= -1 && layout <= 2, RCFM_ERR_ARG, "layout: -1 automatic, 0 plain, 1 tile-blocked, 2 padded rows");
         static std::mutex mu;
         static std::map<std::vector<int64_t>, std::unique_ptr<FftEngine>> engines;
-        static DeviceBuffer tmp;
+        static DeviceBuffer tmp, tmp2;
         std::lock_guard<std::mutex> lock(mu);
         std::vector<int64_t> key(pass_lengths, pass_lengths + npass);
+        key.push_back(layout);
         auto it = engines.find(key);
-        if (it == engines.end()) it = engines.emplace(key, std::make_unique<FftEngine>(n, pass_lengths, npass)).first;
-        RC_REQUIRE(it->second->desc().n == n, RCFM_ERR_ARG, "the pass lengths do not multiply to n");
-        tmp.reserve((size_t)batch * it->second->tmp_stride() * sizeof(float2));
-        it->second->c2c(static_cast<const float2*>(in), static_cast<float2*>(out), tmp.as<float2>(), batch,
-                        inverse != 0, 1.0f, as_stream(stream));
+        if (it == engines.end()) it = engines.emplace(key, std::make_unique<FftEngine>(n, pass_lengths, npass, layout)).first;
+        const FftEngine& e = *it->second;
+        RC_REQUIRE(e.desc().n == n, RCFM_ERR_ARG, "the pass lengths do not multiply to n");
+        tmp.reserve((size_t)batch * e.tmp_stride() * sizeof(float2));
+        // the padded-rows layout's intermediates do not fit `out`: a second scratch array, so that (like the default plan
+        // of a transform beyond the Infinity Cache) no pass runs in place
+        const bool second = layout == 2 && (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20);
+        if (second) tmp2.reserve((size_t)batch * e.tmp_stride() * sizeof(float2));
+        e.c2c(static_cast<const float2*>(in), static_cast<float2*>(out), tmp.as<float2>(), batch, inverse != 0, 1.0f,
+              as_stream(stream), nullptr, second ? tmp2.as<float2>() : nullptr);
     });
 }
 

@@ -50,6 +50,11 @@ struct FftPass {
     // fit the Infinity Cache writes each of its tiles as ONE contiguous run (out_t = 16 L, out_k = 16) instead of L
     // segments a row pitch of megabytes apart, and the second pass reads that layout (fft_engine.hip).
     int64_t in_t, out_t;
+    // 1: the launch walks (o1, o2, tile) as ONE flat tile index in XCD-aware order (each XCD owns a contiguous eighth of
+    // all tiles) instead of grid.y = outer lines: for passes whose neighbouring tiles share 128-byte lines although
+    // their rows are short (the padded-rows layout's first pass: rows of 37.5 lines, fft_plan_describe layout 2).
+    int32_t flat_outer;
+    int32_t reserved_;
 };
 
 struct FftPlanDesc {
@@ -68,10 +73,21 @@ struct FftPlanDesc {
 // fall back to rocFFT.
 // max_l (<= kFftMaxL, 0 = default) caps the per-pass length; tests use it to force deep plans.
 // `forced` (nforced factors whose product is n) overrides the planner's choice of pass lengths.
-// `blocked`: the tile-blocked hand-over between the first two passes of a three-pass plan (FftPass::out_t): -1 = when
-// the transform does not fit the Infinity Cache (the default), 0 = never, 1 = whenever the lengths allow it (tests).
+// `layout` of the intermediate arrays of a three-pass plan:
+//   -1  the engine decides: tile-blocked hand-over between the first two passes (FftPass::out_t) when the transform does
+//       not fit the Infinity Cache, else plain
+//    0  plain: every strided pass writes where it read (safe in place)
+//    1  tile-blocked whenever the lengths allow it (tests)
+//    2  padded rows: the scratch rows of n_3 points get a pitch of whole 128-byte lines ([k_1][k_2][pitch]) -- a PRIVATE
+//       layout (tmp_stride = n_1 n_2 pitch > n, never the caller's in / out) that lets an order of the pass lengths
+//       whose LAST pass stores aligned segments (n_1 n_2 a multiple of 16) keep every other write and all reads but the
+//       first pass's aligned too, even when n_3 is not a multiple of 16 (N = 2.4e8 as 640 x 625 x 600: pitch 608)
 bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l = 0, const int64_t* forced = nullptr,
-                       int nforced = 0, int blocked = -1);
+                       int nforced = 0, int layout = -1);
+
+// For a three-pass default plan whose last pass stores segments that straddle 128-byte lines (n_1 n_2 not a multiple of
+// 16): an order of the same three lengths with aligned stores, to be run in layout 2.  false: none / not needed.
+bool fft_plan_aligned_order(const FftPlanDesc& plan, int64_t* lengths);
 
 // Device-side view of one pass, handed to the kernel by value.
 struct FftPassDev {
@@ -82,6 +98,11 @@ struct FftPassDev {
     float fine_step;          // 2 pi / n
     int fine_bits;
     int64_t in_batch, out_batch;
+    // Experiment build -DRCFM_TW_TABLE=1 (profiles/r06_*_twiddle_table.md): the inter-pass twiddles of a two-pass plan's first
+    // pass as a full table, tw_full[k * n_inner + i] = W_n^(i k) -- one 8-byte load per output (lanes along i: whole
+    // 128-byte segments, 8 n bytes per plan that stay in the L2s) instead of a coarse-table entry + series per butterfly and
+    // a running product per output.  nullptr: computed (the default build never sets it).
+    const float2* tw_full = nullptr;
 };
 
 // Rows of the transform's output to keep (row r = output elements [r n_1, (r+1) n_1), n_1 = the plan's first
@@ -98,7 +119,7 @@ class FftEngine {
     explicit FftEngine(int64_t n);
     // Same transform with the pass lengths given (e.g. the planner's two factors swapped, so that
     // this plan's last pass tiles exactly like another plan's first pass: fused_passes.h).
-    FftEngine(int64_t n, const int64_t* factors, int nfactors);
+    FftEngine(int64_t n, const int64_t* factors, int nfactors, int layout = -1);
     // The plan in the PLAIN layout (every strided pass keeps the layout it reads: safe in place, what every fused caller
     // of pass_dev() assumes).  desc_blocked() is the same plan with the tile-blocked hand-over between its first two
     // passes (FftPass::in_t / out_t) when the planner chose one -- c2c() runs it only when no pass runs in place.
@@ -114,13 +135,18 @@ class FftEngine {
     // inverse = conjugate transform (no 1/n); every output is multiplied by `scale`.
     // keep (forward transforms only): the last pass stores only those rows of the output; the rest of
     // `out` is left untouched.
+    // tmp2 (optional, tmp_stride() elements per signal, distinct from everything else): a second scratch array -- a
+    // three-pass plan then runs in -> tmp2 -> tmp -> out with no pass in place (what the padded-rows layout, whose
+    // intermediates do not fit `out`, needs to ping-pong).
     void c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
-             hipStream_t stream, const FftRowWindow* keep = nullptr) const;
+             hipStream_t stream, const FftRowWindow* keep = nullptr, float2* tmp2 = nullptr) const;
     int64_t row_length() const { return desc_.pass[0].L; }   // n_1
     FftPassDev pass_dev(int t, int64_t in_batch, int64_t out_batch, bool blocked = false) const;
     static size_t lds_bytes(int L);
     static dim3 grid(const FftPass& p, int batch);
     static int compute_units();   // CUs of the current device (256 on MI355X)
+    // -DRCFM_TW_TABLE experiment: builds the full inter-pass twiddle table of pass 0 (two-pass plans); pass_dev(0, ...) carries it
+    void enable_twiddle_table() const;
 
    private:
     void build_tables();
@@ -131,6 +157,7 @@ class FftEngine {
     DeviceBuffer stage_tw_[kFftMaxPasses];
     DeviceBuffer pos_[kFftMaxPasses];
     DeviceBuffer coarse_;
+    mutable DeviceBuffer tw_full_;
 };
 
 }  // namespace rcfm

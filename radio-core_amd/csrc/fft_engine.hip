@@ -144,7 +144,31 @@ bool hand_over_blocked(int64_t n, const int64_t* f, bool any_size) {
 
 }  // namespace
 
-bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* forced, int nforced, int blocked) {
+bool fft_plan_aligned_order(const FftPlanDesc& plan, int64_t* lengths) {
+    if (plan.npass != 3 || (size_t)plan.n * sizeof(float2) <= ((size_t)256 << 20)) return false;
+    const int64_t f[3] = {plan.pass[0].L, plan.pass[1].L, plan.pass[2].L};
+    if ((f[0] * f[1]) % 16 == 0) return false;   // the default order already stores aligned segments
+    double best = 1e300;
+    bool ok = false;
+    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    for (auto& pm : perm) {
+        const int64_t a = f[pm[0]], b = f[pm[1]], c = f[pm[2]];
+        if (a % 16 != 0 || (a * b) % 16 != 0) continue;       // whole tiles over k_1, aligned output stride
+        const int64_t pitch = (c + 15) / 16 * 16;
+        const double cost = (double)pitch / (double)c + 0.02 * (double)a / (double)std::min(a, std::min(b, c));
+        if (cost < best) {
+            best = cost;
+            ok = true;
+            lengths[0] = a;
+            lengths[1] = b;
+            lengths[2] = c;
+        }
+    }
+    return ok;
+}
+
+bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* forced, int nforced, int layout) {
+    const int blocked = layout == 2 ? 0 : layout;
     const bool default_cap = (max_l <= 0);
     if (max_l <= 0 || max_l > kFftMaxL) max_l = kFftMaxL;
     if (n < 256 || n >= (int64_t(1) << 32) || !smooth235(n)) return false;
@@ -260,6 +284,31 @@ bool fft_plan_describe(int64_t n, FftPlanDesc* out, int max_l, const int64_t* fo
         d.pass[1].in_l = f[2] * f[0];
     }
     d.tmp_stride = n;
+    if (layout == 2) {
+        // Padded rows (fft_engine.h): scratch element (k_1 | l_1, k_2 | l_2, j_2) at (k_1 n_2 + k_2) pitch + j_2.  The first
+        // pass reads the natural-order input -- line (l_2, j_2) starts at l_2 n_3 + j_2, so for n_3 = 8 mod 16 half of its
+        // segments straddle lines (reads only; neighbouring tiles share those lines: flat_outer) -- every other access of
+        // the three passes is a whole aligned 128-byte segment.
+        if (np != 3) return false;
+        const int64_t pitch = (f[2] + 15) / 16 * 16;
+        FftPass& p0 = d.pass[0];
+        p0.n_o1 = f[1];
+        p0.n_inner = f[2];
+        p0.in_o1 = f[2];
+        p0.in_l = f[1] * f[2];
+        p0.out_o1 = pitch;
+        p0.out_k = f[1] * pitch;
+        p0.tw_o1 = f[2] * p0.tw_i;
+        p0.flat_outer = 1;
+        FftPass& p1 = d.pass[1];
+        p1.n_inner = f[2];
+        p1.in_o1 = p1.out_o1 = f[1] * pitch;
+        p1.in_l = p1.out_k = pitch;
+        FftPass& p2 = d.pass[2];
+        p2.in_i = f[1] * pitch;
+        p2.in_o1 = pitch;
+        d.tmp_stride = f[0] * f[1] * pitch;
+    }
     if (np == 2 && (f[1] % 16) != 0) {
         const int64_t pitch = (f[1] + 15) / 16 * 16;
         d.pass[0].out_k = pitch;     // row k_1 of the scratch starts at k_1 * pitch
@@ -292,8 +341,8 @@ FftEngine::FftEngine(int64_t n) {
     build_tables();
 }
 
-FftEngine::FftEngine(int64_t n, const int64_t* factors, int nfactors) {
-    RC_REQUIRE(fft_plan_describe(n, &desc_blk_, 0, factors, nfactors), RCFM_ERR_ARG,
+FftEngine::FftEngine(int64_t n, const int64_t* factors, int nfactors, int layout) {
+    RC_REQUIRE(fft_plan_describe(n, &desc_blk_, 0, factors, nfactors, layout), RCFM_ERR_ARG,
                "pass lengths not supported by the FFT engine");
     split_layouts();
     build_tables();
@@ -356,11 +405,25 @@ FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch, bool 
     d.fine_bits = desc_.fine_bits;
     d.in_batch = in_batch;
     d.out_batch = out_batch;
+    d.tw_full = (t == 0 && tw_full_.bytes() != 0) ? tw_full_.as<float2>() : nullptr;
     return d;
 }
 
+void FftEngine::enable_twiddle_table() const {
+    if (tw_full_.bytes() != 0 || desc_.npass != 2) return;
+    const FftPass& p = desc_.pass[0];
+    const int64_t n = desc_.n;
+    std::vector<float2> tw((size_t)p.L * (size_t)p.n_inner);
+    for (int64_t k = 0; k < p.L; ++k)
+        for (int64_t i = 0; i < p.n_inner; ++i) {
+            const double a = -kTwoPi * (double)((i * p.tw_i * k) % n) / (double)n;
+            tw[(size_t)(k * p.n_inner + i)] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    tw_full_.upload(tw.data(), tw.size() * sizeof(float2));
+}
+
 void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,
-                    hipStream_t stream, const FftRowWindow* keep) const {
+                    hipStream_t stream, const FftRowWindow* keep, float2* tmp2) const {
     if (batch <= 0) return;
     const int np = desc_.npass;
     const int64_t n = desc_.n;
@@ -377,7 +440,10 @@ void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool 
                            (size_t)n * (size_t)batch * sizeof(float2) > ((size_t)256 << 20);
     // The tile-blocked hand-over (pass 1 reads another address set than it writes) only when no pass runs in place.
     const bool blk = ping_pong && has_blk_;
+    // a second scratch array: in -> tmp2 -> tmp -> out (three passes; the padded-rows layout's way not to run in place)
+    const bool two_scratch = np == 3 && tmp2 != nullptr && tmp2 != tmp && tmp2 != in && tmp2 != out && !ping_pong;
     auto mid = [&](int t) -> float2* {   // where pass t < np - 1 writes
+        if (two_scratch) return t == 0 ? tmp2 : tmp;
         if (!ping_pong) return tmp;
         return ((np - 2 - t) & 1) ? out : tmp;
     };

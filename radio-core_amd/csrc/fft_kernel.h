@@ -627,9 +627,18 @@ __global__ __launch_bounds__(T, (big_tile_pair(L) ? 8 : triple_tile(L) ? 6 : T *
     const int w = tid & (W - 1), rg = tid >> kLogW;
     const VBlock vb = vblock_hw();
     LineId id;
-    const BlockPos bp = block_pos(vb);
+    BlockPos bp = block_pos(vb);
     id.batch = bp.batch;
-    const unsigned o = vb.y, n_o2 = (unsigned)p.n_o2;
+    unsigned o = vb.y;
+    const unsigned n_o2 = (unsigned)p.n_o2;
+    if (p.flat_outer) {
+        // one flat tile index over (outer lines, tiles of a row), dealt to the XCDs in contiguous eighths by block_pos
+        // (the launch rounds the count up to a multiple of 8: the surplus workgroups leave here, before any barrier)
+        const unsigned tiles_inner = ((unsigned)p.n_inner + W - 1) / W;
+        o = bp.tile / tiles_inner;
+        if (o >= (unsigned)(p.n_o1 * p.n_o2)) return;
+        bp.tile -= o * tiles_inner;
+    }
     id.o1 = n_o2 == 1 ? o : o / n_o2;
     id.o2 = n_o2 == 1 ? 0 : o - (unsigned)id.o1 * n_o2;
     const int i0 = (int)bp.tile * W;
@@ -989,6 +998,24 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
     }
     lds_barrier();
 
+#if defined(RCFM_TW_TABLE) && RCFM_TW_TABLE
+    // experiment: the inter-pass twiddle of every output this thread will store, fetched now (L2 hits) and consumed after
+    // the second transform's stages
+    float2 twv[nitL * RL];
+    {
+        const float2* twt = d2.tw_full + (i0 + (w < wvalid ? w : 0));
+        const unsigned tw_pitch = (unsigned)p2.n_inner;
+#pragma unroll
+        for (int it = 0; it < nitL; ++it) {
+            int g = rg + RG * it;
+            if (rowsL % RG != 0) g = g < rowsL ? g : 0;
+            const int kb = kbase(g);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) twv[it * RL + q] = twt[(unsigned)(kb + (L / RL) * q) * tw_pitch];
+        }
+    }
+#endif
+
     // ---- second transform: a strided pass of plan 2 whose input already sits in LDS ----------
     stage_lds<L, R0, L, true, RG, true, false, kZeroQ>(tile, tw, w, rg);
     lds_barrier();
@@ -1000,9 +1027,29 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
         stage_lds<L, R2, L / (R0 * R1), true, RG>(tile, tw, w, rg);
         lds_barrier();
     }
+    const bool lane_ok = w < wvalid;
+#if defined(RCFM_TW_TABLE) && RCFM_TW_TABLE
+#pragma unroll
+    for (int it = 0; it < nitL; ++it) {
+        const int g = rg + RG * it;
+        if ((rowsL % RG == 0) || g < rowsL) {
+            float2 x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
+            dft_p<RL>(x);
+            const int kb = kbase(g);
+            if (lane_ok) {
+#pragma unroll
+                for (int q = 0; q < RL; ++q) {
+                    const int k = kb + (L / RL) * q;
+                    store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, cmul(x[dft_slot<RL>(q)], twv[it * RL + q]));
+                }
+            }
+        }
+    }
+#else
     const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
     const float2 D = big_twiddle(d2, f * (unsigned)(L / RL));
-    const bool lane_ok = w < wvalid;
 #pragma unroll
     for (int it = 0; it < nitL; ++it) {
         const int g = rg + RG * it;
@@ -1024,6 +1071,7 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
             }
         }
     }
+#endif
 }
 
 // ---- one inverse transform in, two forward transforms out ------------------------------
@@ -1566,7 +1614,9 @@ inline void launch_fft_pass(const FftPassDev& d, int batch, const LoadOp& ld, co
     const bool shape_ok = (rows || d.p.in_i == 1) && d.p.out_i == 1 && ((d.p.has_twiddle != 0) == !rows) &&
                           d.p.n_o1 * d.p.n_o2 <= 65535 && batch <= 65535;
     if (shape_ok) {
-        const dim3 grid((unsigned)((d.p.n_inner + W - 1) / W), (unsigned)(d.p.n_o1 * d.p.n_o2), (unsigned)batch);
+        const unsigned tiles_inner = (unsigned)((d.p.n_inner + W - 1) / W), outer = (unsigned)(d.p.n_o1 * d.p.n_o2);
+        const dim3 grid = d.p.flat_outer ? dim3((tiles_inner * outer + 7u) / 8u * 8u, 1, (unsigned)batch)
+                                         : dim3(tiles_inner, outer, (unsigned)batch);
         switch (d.p.L) {
 #define RCFM_CASE(LEN, A, B, C, D)                                                                            \
     case LEN:                                                                                                 \

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("RCFM_LIB") or os.path.join(os.path.dirname(_HERE), "_
 RCFM_FM, RCFM_MFM, RCFM_WBFM = 0, 1, 2
 RCFM_OPT_LDS_CHAIN, RCFM_OPT_FUSED_TILES, RCFM_OPT_PHASE_LINK, RCFM_OPT_NARROW_TILES, RCFM_OPT_STATE_FENCE = 1, 2, 3, 4, 5   # rcfm_demod_set_option
 RCFM_OPT_PILOT_CHAIN, RCFM_OPT_DECIM_TILE, RCFM_OPT_LDS_DEEMPH, RCFM_OPT_PILOT_BLOCKED, RCFM_OPT_GRAPH = 6, 7, 8, 9, 10
-RCFM_TUNER_OPT_NARROW_TILES = 1                                                                                                # rcfm_tuner_set_option
+RCFM_TUNER_OPT_NARROW_TILES, RCFM_TUNER_OPT_ALIGNED_PLAN = 1, 2                                                                                                # rcfm_tuner_set_option
 
 _ERR_SIZE, _ERR_INDEX, _ERR_RUNTIME, _ERR_ARG, _ERR_STATE = -1, -2, -3, -4, -5
 
@@ -101,7 +101,7 @@ SIGNATURES = {
     "rcfm_fft_describe": [_i64, _i, _vp],
     "rcfm_fft_describe_plan": [_i64, ctypes.POINTER(_i64), _i, _i, _vp],
     "rcfm_fft_c2c": [_i64, _i, _i, _vp, _vp, _vp],
-    "rcfm_fft_c2c_plan": [_i64, ctypes.POINTER(_i64), _i, _i, _i, _vp, _vp, _vp],
+    "rcfm_fft_c2c_plan": [_i64, ctypes.POINTER(_i64), _i, _i, _i, _i, _vp, _vp, _vp],
     "rcfm_fft_c2c_rocfft": [_i64, _i, _i, _vp, _vp, _vp],
     "rcfm_profile_stage_count": [],
     "rcfm_profile_enable": [ctypes.c_uint64],
@@ -118,7 +118,8 @@ class FftPass(ctypes.Structure):
                 ("in_o1", _i64), ("in_o2", _i64), ("in_i", _i64), ("in_l", _i64),
                 ("out_o1", _i64), ("out_o2", _i64), ("out_i", _i64), ("out_k", _i64),
                 ("tw_o1", _i64), ("tw_o2", _i64), ("tw_i", _i64),
-                ("has_twiddle", ctypes.c_int32), ("load_along_l", ctypes.c_int32), ("in_t", _i64), ("out_t", _i64)]
+                ("has_twiddle", ctypes.c_int32), ("load_along_l", ctypes.c_int32), ("in_t", _i64), ("out_t", _i64),
+                ("flat_outer", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
 class FftPlan(ctypes.Structure):
@@ -131,14 +132,17 @@ _lib = None
 _torch = None
 
 
-def load_library(path=LIB_PATH):
-    """dlopen librcfm.so and declare every prototype of include/rcfm.h."""
+def load_library(path=LIB_PATH, strict=True):
+    """dlopen librcfm.so and declare every prototype of include/rcfm.h + rcfm_tools.h.  strict=False (tools/ab_libs.py: an
+    older build beside the current one) skips entry points that build does not export."""
     if not os.path.exists(path):
         raise ImportError(
             "librcfm.so not found at %s -- build it with `make -C radio-core_amd` "
             "(or __graft_entry__.build()); there is no CPU fallback" % path)
     lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
+        if not strict and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _i

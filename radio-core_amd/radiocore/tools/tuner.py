@@ -376,6 +376,12 @@ class Tuner(Injector):
             return None
         return kind, demod._input_size, demod._output_size, demod._tau
 
+    def reset_states(self):
+        """Every channel's de-emphasis state back to the reference's freshly constructed filters (deemphasis.py:48-49):
+        the batched handles of run_all / run_each, whose slots the channels' demodulator objects share."""
+        for h in self._batched.values():
+            hip.check(self._lib.rcfm_demod_reset_state(h.value, hip.stream()))
+
     def set_kernel_options(self, lds_chain=True, fused_tiles=True, phase_link=True, narrow_tiles=1):
         """Which forms of the kernel chain run_all / run_each may use (rcfm_demod_set_option; no reference
         counterpart).  The audio does not depend on them beyond float32 rounding: switching all three off gives a

@@ -21,7 +21,8 @@ def describe(n, max_l=0):
 
 
 def describe_plan(n, lengths, blocked=-1):
-    """The plan for given pass lengths (rcfm_fft_describe_plan); blocked = 1 forces the tile-blocked hand-over."""
+    """The plan for given pass lengths (rcfm_fft_describe_plan); `blocked` is its layout argument: -1 automatic, 0 plain,
+    1 forces the tile-blocked hand-over, 2 the padded-rows layout."""
     from radiocore._internal import hip
     lib = hip.load_library()
     plan = hip.FftPlan()

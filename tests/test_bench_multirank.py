@@ -60,6 +60,12 @@ def test_two_rank_dry_run_prints_one_contract_line(parallelism):
         assert 1.0 < r["amdahl_bound_speedup"] < 2.0
     g = r["gather_check"]
     assert g["finite"] and g["own_block_equal"] and g["blocks_with_audio"] == g["blocks"] == 2
+    # the same launch timed ONE rank first (rank 0 alone) and kept its audio: this partitioning reproduced it bit for bit
+    assert r["n1"]["value"] > 0 and r["n1"]["steps"] == 3
+    assert abs(r["speedup_vs_n1"] - r["value"] / r["n1"]["value"]) <= 1e-3 * r["speedup_vs_n1"]
+    sc = r["self_check"]
+    assert sc["bit_identical"] is True and sc["max_abs_diff"] == 0.0 and sc["peak"] > 1e-3 and sc["channels"] == r["config"]["channels"]
+    assert "partitionings" not in r                                  # one leg: nothing to choose between
     # where each rank's time went: one row per rank, the keys a first multi-GPU run is debugged with
     rows = r["per_rank"]
     assert [row["rank"] for row in rows] == [0, 1]
@@ -91,8 +97,8 @@ def test_a_stalled_rank_fails_loudly_instead_of_hanging():
 @pytest.mark.timeout(900)
 def test_plain_python_launch_starts_its_own_ranks_and_reports_both_partitionings():
     """`python bench.py --gpus 2` with NO launcher around it (how the driver starts N = 1): bench.py re-executes itself
-    under torch.distributed.run with two ranks, rank 0 prints ONE line with n_gpus == 2, the replicated partitioning as
-    `value` and the rotating owner in the `rotating` block of the same launch."""
+    under torch.distributed.run with two ranks, rank 0 prints ONE line with n_gpus == 2 whose
+    `value` is the faster verified partitioning, the other one in its own block of the same line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(RCFM_BENCH_DEVICE="0", RCFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "small"]
@@ -102,15 +108,31 @@ def test_plain_python_launch_starts_its_own_ranks_and_reports_both_partitionings
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and len(r["per_rank"]) == 2
-    assert "wideband FFT replicated" in r["config"]["parallelism"] and 1.0 < r["amdahl_bound_speedup"] < 2.0
-    rot = r["rotating"]
-    assert "error" not in rot, rot
-    assert rot["value"] > 0 and rot["ms_per_step"] > 0 and len(rot["per_rank"]) == 2
-    assert "rotating FFT owner" in rot["parallelism"] and rot["amdahl_bound_speedup"] == 2.0
-    assert rot["gather_check"]["finite"] and rot["gather_check"]["blocks_with_audio"] == 2
-    assert rot["rotating_owner"]["lookahead"] == 2 and rot["vs_replicated"] > 0
+    # the chosen-`value` rule: both legs verified -> the FASTER one is the line, the other keeps its own block
+    pt = r["partitionings"]
+    assert pt["verified"] == {"replicated": True, "rotating": True}
+    fastest = max(pt["value"], key=pt["value"].get)
+    assert pt["published"] == fastest and r["value"] == pt["value"][fastest]
+    other = "rotating" if fastest == "replicated" else "replicated"
+    assert other in r and fastest not in r
+    assert ("rotating FFT owner" if fastest == "rotating" else "wideband FFT replicated") in r["config"]["parallelism"]
+    assert abs(r["value"] - r["config"]["wideband_samples"] / (r["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * r["value"]
+    blk = r[other]
+    assert "error" not in blk, blk
+    assert blk["value"] == pt["value"][other] and blk["ms_per_step"] > 0 and len(blk["per_rank"]) == 2
+    assert abs(blk["vs_published"] - blk["value"] / r["value"]) <= 1e-3
+    assert ("rotating FFT owner" if other == "rotating" else "wideband FFT replicated") in blk["parallelism"]
+    rot, rep = (r, blk) if fastest == "rotating" else (blk, r)
+    assert rot["amdahl_bound_speedup"] == 2.0 and 1.0 < rep["amdahl_bound_speedup"] < 2.0
+    assert rot["rotating_owner"]["lookahead"] == 2
     for row in rot["per_rank"]:
         assert row["owned_buffers"] >= 1
+    for leg in (rot, rep):
+        assert leg["gather_check"]["finite"] and leg["gather_check"]["blocks_with_audio"] == 2
+        assert leg["self_check"]["bit_identical"] is True            # one buffer through each: the single-GPU audio
+    # one GPU in the same launch, and the published speed-up against it
+    assert r["n1"]["value"] > 0 and abs(r["speedup_vs_n1"] - r["value"] / r["n1"]["value"]) <= 1e-3 * r["speedup_vs_n1"]
+    assert r["rccl_ranks"] == 0 and r["cpu_baseline"] is None
 
 
 @pytest.mark.timeout(300)
@@ -129,3 +151,5 @@ def test_a_failing_rotating_leg_still_publishes_the_replicated_line():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0
     assert "error" in r["rotating"] and r["rotating"]["rank"] == 0 and r["rotating"]["phase"]
+    assert "wideband FFT replicated" in r["config"]["parallelism"] and "partitionings" not in r
+    assert r["self_check"]["bit_identical"] is True and r["speedup_vs_n1"] > 0

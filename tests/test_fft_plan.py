@@ -101,3 +101,35 @@ def test_a_blocked_middle_pass_may_not_run_in_place(lengths):
     got, same_set = fft_model.model_fft_middle_in_place(x, blocked)
     assert not same_set
     assert np.max(np.abs(got - want)) > 1e-3 * np.max(np.abs(want))     # garbage, as the advisor's simulation found
+
+
+@pytest.mark.parametrize("lengths", [(16, 20, 24), (32, 25, 40), (16, 16, 600)])
+def test_padded_rows_layout(lengths):
+    """Layout 2 (fft_engine.h): the scratch rows of n_3 points at a pitch of whole 128-byte lines, [k_1][k_2][pitch] -- the
+    layout the tuner's aligned plan (N = 2.4e8 as 640 x 625 x 600, pitch 608) runs in.  The plan is an FFT; every write of
+    the first two passes and every read of the last two starts on a 16-point boundary; only the first pass's reads do
+    not; its launch is flat (XCD-aware over all tiles)."""
+    n = lengths[0] * lengths[1] * lengths[2]
+    plan = fft_model.describe_plan(n, lengths, blocked=2)
+    assert plan is not None
+    pitch = (lengths[2] + 15) // 16 * 16
+    assert plan.tmp_stride == lengths[0] * lengths[1] * pitch
+    p0, p1, p2 = plan.passes[0], plan.passes[1], plan.passes[2]
+    assert p0.flat_outer == 1 and p1.flat_outer == 0 and p2.flat_outer == 0
+    assert (p0.n_o1, p0.n_inner, p0.in_o1, p0.in_l) == (lengths[1], lengths[2], lengths[2], lengths[1] * lengths[2])
+    assert p0.out_o1 % 16 == 0 and p0.out_k % 16 == 0
+    assert p1.in_o1 % 16 == 0 and p1.in_l % 16 == 0 and p1.out_o1 % 16 == 0 and p1.out_k % 16 == 0
+    assert p2.in_i % 16 == 0 and p2.in_o1 % 16 == 0
+    assert p2.out_k % 16 == 0 or (lengths[0] * lengths[1]) % 16 != 0
+    r = np.random.default_rng(n)
+    x = r.standard_normal(n) + 1j * r.standard_normal(n)
+    got = fft_model.model_fft(x, plan)
+    want = np.fft.fft(x)
+    assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+    # the middle pass keeps its addresses: the plan also runs with ONE scratch array (middle pass in place)
+    got, same_set = fft_model.model_fft_middle_in_place(x, plan)
+    assert same_set and np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+
+
+def test_padded_rows_layout_is_for_three_passes():
+    assert fft_model.describe_plan(240000, (480, 500), blocked=2) is None

@@ -174,7 +174,7 @@ def test_only_tuner_and_demodulator_handles_draw_from_a_bound_arena():
     y = torch.empty_like(x)
     hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(x), hip.ptr(y), hip.stream()))
     lens = (ctypes.c_int64 * 3)(64, 128, 128)
-    hip.check(lib.rcfm_fft_c2c_plan(n, lens, 3, 1, 0, hip.ptr(x), hip.ptr(y), hip.stream()))
+    hip.check(lib.rcfm_fft_c2c_plan(n, lens, 3, -1, 1, 0, hip.ptr(x), hip.ptr(y), hip.stream()))
     p = torch.randn(4, 240000, device="cuda")
     z = torch.empty(4, 240000, 2, device="cuda")
     hip.check(lib.rcfm_hilbert(4, 240000, hip.ptr(p), hip.ptr(z), hip.stream()))

@@ -447,6 +447,9 @@ def _stages_run(lib, hip):
     ("WBFM", 200000, 50000),   # 500 x 400, L2 = 100 (the planner's order 400 x 500 would need L2 = 125: swapped)
     ("WBFM", 240000, 24000),   # 480 x 500, L2 = 50
     ("WBFM", 192000, 48000),   # 480 x 400, L2 = 100
+    ("WBFM", 250000, 48000),   # the reference's own single-station example (examples/receive_fm.py:18-19): 500 x 500, L2 = 96
+    ("MFM", 250000, 48000),
+    ("FM", 250000, 48000),
     ("MFM", 256000, 32000),
     ("FM", 200000, 40000),
     ("MFM", 25000, 8000),      # 25 kHz narrow-band channels: 100 x 250, L2 = 80
@@ -489,6 +492,46 @@ def test_fused_chain_on_other_geometries(rc, oracle, kind, B, A):
     assert ran["audio_spectrum"] == 0, ran            # the decimation never ran as a kernel of its own
     if kind == "WBFM":
         assert ran["ifft_A"] == 0 and ran["fft_B"] > 0 and ran["hilbert_mask"] == 0 and ran["stereo_mix"] == 0, ran
+
+
+PATH_MAP_B = (240000, 250000, 256000)
+PATH_MAP_A = (32000, 44100, 48000)
+
+
+@pytest.mark.parametrize("A", PATH_MAP_A)
+@pytest.mark.parametrize("B", PATH_MAP_B)
+def test_path_map_cells_against_the_oracle(rc, oracle, B, A):
+    """Every cell of bench.py's `other_configs.path_map` (WBFM, B in {240 000, 250 000, 256 000} x A in {32 000, 44 100,
+    48 000}) at reduced N against the reference loop, two buffers: whichever route a geometry takes -- two-transform
+    tiles, the run-time decimating tile, separate transforms, or rocFFT for every demodulator transform when A has a
+    prime factor above 5 (44 100 = 2^2 3^2 5^2 7^2) -- the audio is the reference's."""
+    from radiocore._internal import hip
+    lib = hip.lib()
+    C = 3
+    raster = int(B * 1.25)
+    N = 10 * raster
+    centres = workloads.channel_grid(C, raster)
+    tuner, ref = _pair(rc, oracle, "WBFM", centres, B, A, N)
+    hip.check(lib.rcfm_profile_enable((1 << lib.rcfm_profile_stage_count()) - 1))
+    hip.check(lib.rcfm_profile_reset())
+    try:
+        for buf in range(2):
+            x = np.roll(workloads.wideband(N, ref.input_frequency, centres, B, gain=0.4, stereo=True), 733 * buf)
+            tuner.load(x)
+            ref.load(x)
+            audio = tuner.run_all()
+            for c in ref.channels():
+                want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, 2)
+                assert rel_err(audio[c.index], want) <= TOL, (B, A, buf, c.index, rel_err(audio[c.index], want))
+        ran = _stages_run(lib, hip)
+    finally:
+        hip.check(lib.rcfm_profile_enable(0))
+    print("path_map cell", B, A, {k: v for k, v in ran.items() if v})
+    smooth = A % 7 != 0                               # 44 100 = 2^2 3^2 5^2 7^2
+    if smooth:
+        assert ran["hilbert_mask"] == 0, ran          # {2,3,5}-smooth: never the rocFFT route
+    else:
+        assert ran["hilbert_mask"] > 0 and ran["stereo_mix"] > 0, ran
 
 
 @pytest.mark.parametrize("narrow", [0, 2])

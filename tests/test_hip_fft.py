@@ -145,7 +145,7 @@ def test_engine_vs_rocfft_four_passes_at_a_billion_points():
     assert err <= 2e-5 * peak, (err, peak)
 
 
-def _run_plan(n, plan, batch, inverse, x):
+def _run_plan(n, plan, batch, inverse, x, layout=-1):
     import ctypes
     import torch
     from radiocore._internal import hip
@@ -153,7 +153,7 @@ def _run_plan(n, plan, batch, inverse, x):
     xd = hip.to_device(x, torch.complex64)
     yd = hip.empty(xd.shape, torch.complex64)
     lens = (ctypes.c_int64 * len(plan))(*plan)
-    hip.check(lib.rcfm_fft_c2c_plan(n, lens, len(plan), batch, int(inverse), hip.ptr(xd), hip.ptr(yd), hip.stream()))
+    hip.check(lib.rcfm_fft_c2c_plan(n, lens, len(plan), layout, batch, int(inverse), hip.ptr(xd), hip.ptr(yd), hip.stream()))
     torch.cuda.synchronize()
     return yd.cpu().numpy()
 
@@ -171,6 +171,56 @@ def test_big_tiles_in_both_roles(n, plan):
     assert rel_err(_run_plan(n, plan, 2, True, want), x * n) <= 4e-6
 
 
+@pytest.mark.parametrize("n,plan,batch", [(960000, (80, 100, 120), 2), (1228800, (128, 80, 120), 1), (9600 * 25, (16, 25, 600), 3)])
+def test_padded_rows_layout_runs(n, plan, batch):
+    """rcfm_fft_c2c_plan layout 2 at sizes numpy checks in a moment: n_3 = 8 mod 16 (120, 600), the first pass over partial
+    last tiles and the flat XCD-aware launch, forward and inverse, batched."""
+    r = np.random.default_rng(n)
+    x = (r.standard_normal((batch, n)) + 1j * r.standard_normal((batch, n))).astype(np.complex64)
+    want = np.fft.fft(x.astype(np.complex128), axis=1).astype(np.complex64)
+    assert rel_err(_run_plan(n, plan, batch, False, x, layout=2), want) <= 2e-6
+    assert rel_err(_run_plan(n, plan, batch, True, want, layout=2), x * n) <= 4e-6
+
+
+def test_aligned_plan_of_the_wideband_transform():
+    """N = 2.4e8: the tuner runs 640 x 625 x 600 in the padded-rows layout (every store aligned) where the default plan
+    600 x 625 x 640 stores half of its last pass's segments across two lines.  Same transform: both against each other
+    bin for bin, through the FFT entry points and through rcfm_tuner_load with the option on and off (halos included)."""
+    import torch
+    from radiocore._internal import hip
+    lib = hip.lib()
+    n = 240_000_000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.view_as_complex(torch.randn(n, 2, generator=g, device="cuda"))
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    hip.check(lib.rcfm_fft_c2c(n, 1, 0, hip.ptr(x), hip.ptr(a), hip.stream()))
+    lens = (ctypes.c_int64 * 3)(640, 625, 600)
+    hip.check(lib.rcfm_fft_c2c_plan(n, lens, 3, 2, 1, 0, hip.ptr(x), hip.ptr(b), hip.stream()))
+    torch.cuda.synchronize()
+    peak = float(torch.max(torch.abs(a)))
+    assert float(torch.max(torch.abs(a - b))) <= 2e-5 * peak
+    del b
+    rolls = (ctypes.c_int64 * 3)(0, 1_000_000, -119_000_000)       # a channel across bin 0, one inside, one at the far end
+    bws = (ctypes.c_int32 * 3)(240000, 240000, 240000)
+    spectra = []
+    for aligned in (1, 0):
+        t = ctypes.c_void_p()
+        hip.check(lib.rcfm_tuner_create(n, 3, rolls, bws, ctypes.byref(t)))
+        hip.check(lib.rcfm_tuner_set_option(t, hip.RCFM_TUNER_OPT_ALIGNED_PLAN, aligned))
+        hip.check(lib.rcfm_tuner_load(t, hip.ptr(x), hip.stream()))
+        X = ctypes.c_void_p()
+        halo, nn = ctypes.c_int64(), ctypes.c_int64()
+        hip.check(lib.rcfm_tuner_spectrum(t, ctypes.byref(X)))
+        hip.check(lib.rcfm_tuner_spectrum_layout(t, ctypes.byref(halo), ctypes.byref(nn)))
+        out = torch.empty(3, 240000, dtype=torch.complex64, device="cuda")
+        hip.check(lib.rcfm_tuner_run(t, 0, 3, hip.ptr(out), hip.stream()))
+        torch.cuda.synchronize()
+        spectra.append(out)
+        hip.check(lib.rcfm_tuner_destroy(t))
+    pk = float(torch.max(torch.abs(spectra[1])))
+    assert pk > 0 and float(torch.max(torch.abs(spectra[0] - spectra[1]))) <= 2e-5 * pk
+
+
 def test_plan_entry_refuses_lengths_that_do_not_multiply_to_n():
     import ctypes
     import torch
@@ -178,4 +228,4 @@ def test_plan_entry_refuses_lengths_that_do_not_multiply_to_n():
     lib = hip.lib()
     x = hip.empty((240000,), torch.complex64)
     lens = (ctypes.c_int64 * 2)(480, 480)
-    assert lib.rcfm_fft_c2c_plan(240000, lens, 2, 1, 0, hip.ptr(x), hip.ptr(x), hip.stream()) != 0
+    assert lib.rcfm_fft_c2c_plan(240000, lens, 2, -1, 1, 0, hip.ptr(x), hip.ptr(x), hip.stream()) != 0

@@ -37,6 +37,7 @@ def test_digest_follows_the_kernel_sources(tmp_path):
     shutil.copytree(os.path.join(ROOT, "radio-core_amd", "csrc"), root / "radio-core_amd" / "csrc")
     os.makedirs(root / "include")
     shutil.copy(os.path.join(ROOT, "include", "rcfm.h"), root / "include" / "rcfm.h")
+    shutil.copy(os.path.join(ROOT, "include", "rcfm_tools.h"), root / "include" / "rcfm_tools.h")
     assert provenance.kernel_source_sha(str(root)) == provenance.kernel_source_sha()
     with open(root / "radio-core_amd" / "csrc" / "kernels.hip", "a") as fh:
         fh.write("// touched\n")

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--stages", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="name:NAME=VALUE -- a demodulator option for one build")
+    ap.add_argument("--tuner-opt", action="append", default=[], help="name:OPTION=VALUE -- rcfm_tuner_set_option (numeric) for one build")
     ap.add_argument("libs", nargs="+", help="name=path")
     args = ap.parse_args()
     hip.torch()
@@ -37,18 +38,22 @@ def main():
     libs = []
     for item in args.libs:
         name, _, path = item.partition("=")
-        libs.append((name, hip.load_library(os.path.abspath(path))))
+        libs.append((name, hip.load_library(os.path.abspath(path), strict=False)))
     opts = {}
     for item in args.opt:
         name, _, rest = item.partition(":")
         opts.setdefault(name, []).append(rest)
+    topts = {}
+    for item in args.tuner_opt:
+        name, _, rest = item.partition(":")
+        topts.setdefault(name, []).append(rest)
     N, C, B, A, raster, kind = bench.CONFIGS[args.config]
     ch = 2 if kind == "WBFM" else 1
     x, centres, f_in = bench.synth_wideband_on_device(N, C, B, raster, kind, base, hip)
     rolls = (ctypes.c_int64 * C)(*[int(f_in - f) for f in centres])
     bws = (ctypes.c_int32 * C)(*([B] * C))
     chunk_ch = min(8192, max(1024, 1024 * 240000 // B))
-    want = int(17.6 * N + 64.0 * min(C, chunk_ch) * B) + (1 << 30)
+    want = int(17.9 * N + 64.0 * min(C, chunk_ch) * B) + (1 << 30)
     block = torch.empty(want, dtype=torch.uint8, device="cuda")
     audio = torch.empty((C, A, ch), dtype=torch.float32, device="cuda")
     s = hip.stream()
@@ -63,6 +68,10 @@ def main():
             hip.check(lib.rcfm_tuner_shard(t, 0, C))
             hip.check(lib.rcfm_demod_create({"FM": 0, "MFM": 1, "WBFM": 2}[kind], C, B, A, 75e-6, 0, ctypes.byref(d)))
             hip.check(lib.rcfm_arena_bind(None))
+            for item in topts.get(name, []):
+                k, _, v = item.partition("=")
+                if hasattr(lib, "rcfm_tuner_set_option"):
+                    hip.check(lib.rcfm_tuner_set_option(t, int(k), int(v)))
             for item in opts.get(name, []):
                 k, _, v = item.partition("=")
                 hip.check(lib.rcfm_demod_set_option(d, bench.DEMOD_OPTIONS[k], int(v)))

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""A/B timing of librcfm's FFT engine vs rocFFT on the hot-path lengths (GPU box)."""
+"""A/B timing of librcfm's FFT engine vs rocFFT on the hot-path lengths (GPU box).
+
+    python tools/bench_fft.py [n[:batch] ...] [--plan f1,f2[,f3] [--layout -1|0|1|2]]
+"""
 import ctypes
 import os
 import sys
@@ -35,6 +38,11 @@ def main():
         k = argv.index("--plan")
         plan = [int(v) for v in argv[k + 1].split(",")]
         del argv[k:k + 2]
+    layout = -1
+    if "--layout" in argv:   # with --plan: 0 plain, 1 tile-blocked hand-over, 2 padded rows (rcfm_tools.h)
+        k = argv.index("--layout")
+        layout = int(argv[k + 1])
+        del argv[k:k + 2]
     if argv:   # lengths from the command line (batch 1 unless n:batch)
         cases = []
         for a in argv:
@@ -45,7 +53,7 @@ def main():
         y = torch.empty_like(x)
         if plan is not None:
             lens = (ctypes.c_int64 * len(plan))(*plan)
-            runs = (("engine", lambda: lib.rcfm_fft_c2c_plan(n, lens, len(plan), batch, 0, hip.ptr(x), hip.ptr(y), hip.stream())),)
+            runs = (("engine", lambda: lib.rcfm_fft_c2c_plan(n, lens, len(plan), layout, batch, 0, hip.ptr(x), hip.ptr(y), hip.stream())),)
         else:
             runs = (("engine", lambda: lib.rcfm_fft_c2c(n, batch, 0, hip.ptr(x), hip.ptr(y), hip.stream())),
                     ("rocfft", lambda: lib.rcfm_fft_c2c_rocfft(n, batch, 0, hip.ptr(x), hip.ptr(y), hip.stream())))

@@ -4,7 +4,9 @@
 # Everything lands under gpurun_out/<tag>*; copy what is to be judged into profiles/ (and run traffic_summary.py --json
 # in the checkout the counters were collected on, so that the provenance stamp matches).
 tag=${1:-set}; R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"; O=gpurun_out; mkdir -p $O
+rm -f $O/oracle_samples.log
 (python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/${tag}_gputests.log
+cat $O/oracle_samples.log >> $O/${tag}_gputests.log 2>/dev/null   # which channels met the oracle this time (tests/test_hip_whole_output.py)
 python bench.py --steps 20 --warmup 3 --profile-all > $O/${tag}_bench.json 2> $O/${tag}_stages.txt
 tools/profile_kernels.sh ${tag}
 tools/profile_kernels.sh ${tag}_cfg3 --config cfg3
