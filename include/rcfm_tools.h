@@ -83,7 +83,7 @@ int rcfm_demod_get_option(rcfm_demod_t d, int option, int* value);
 
 /* Describes how librcfm runs a length-n complex FFT: fills a POD `rcfm_fft_plan`
  * (layout below) and returns 0, or RCFM_ERR_ARG when n is outside the engine
- * (radices other than 2/3/5, n < 256, more than 4 passes): such lengths use rocFFT. */
+ * (prime factors other than 2, 3, 5, 7; n < 256; more than 4 passes): such lengths use rocFFT. */
 typedef struct rcfm_fft_pass {
     int32_t L, nstages, radix[8];
     int64_t n_o1, n_o2, n_inner;

@@ -68,7 +68,7 @@ struct FftPlanDesc {
     FftPass pass[kFftMaxPasses];
 };
 
-// Factorises n (radices 2, 3, 4, 5, 6, 8, 10) into passes.  Returns false when n has
+// Factorises n (radices 2, 3, 4, 5, 6, 7, 8, 10) into passes.  Returns false when n has
 // another prime factor, is too small to tile, or does not fit 4 passes; callers then
 // fall back to rocFFT.
 // max_l (<= kFftMaxL, 0 = default) caps the per-pass length; tests use it to force deep plans.

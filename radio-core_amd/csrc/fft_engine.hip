@@ -32,7 +32,7 @@ bool choose_radices(int L, int* radix, int* nstages) {
 #undef RCFM_CASE
         default: break;
     }
-    static const int kRadix[] = {10, 8, 6, 5, 4, 3, 2};
+    static const int kRadix[] = {10, 8, 7, 6, 5, 4, 3, 2};
     int rem = L, ns = 0;
     while (rem > 1) {
         bool found = false;
@@ -62,8 +62,8 @@ bool is_fast_length(int64_t L) {
     }
 }
 
-bool smooth235(int64_t n) {
-    for (int p : {2, 3, 5})
+bool smooth235(int64_t n) {   // (and 7 since round 6: the generic tile kernel has a radix-7 butterfly)
+    for (int p : {2, 3, 5, 7})
         while (n % p == 0) n /= p;
     return n == 1;
 }

@@ -131,6 +131,29 @@ __device__ __forceinline__ void dft5(float2& x0, float2& x1, float2& x2, float2&
     x3 = cadd_pi(t2, u2);
 }
 
+// Radix 7 (round 6: audio rates with a factor 7 -- 44 100 = 2^2 3^2 5^2 7^2 = 210 x 210 -- stay inside the engine instead
+// of sending every demodulator transform to rocFFT): y[k] = x0 + sum_j c(jk) a_j - i sum_j s(jk) b_j with a_j = x_j + x_{7-j},
+// b_j = x_j - x_{7-j}, c / s = cos / sin(2 pi m / 7).
+__device__ __forceinline__ void dft7(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4, float2& x5, float2& x6) {
+    constexpr float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+    constexpr float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+    const float2 a1 = cadd(x1, x6), a2 = cadd(x2, x5), a3 = cadd(x3, x4);
+    const float2 b1 = csub(x1, x6), b2 = csub(x2, x5), b3 = csub(x3, x4);
+    const float2 t1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, x0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+    const float2 t2 = make_float2(x0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, x0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+    const float2 t3 = make_float2(x0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, x0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+    const float2 u1 = make_float2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
+    const float2 u2 = make_float2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
+    const float2 u3 = make_float2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
+    x0 = cadd(x0, cadd(a1, cadd(a2, a3)));
+    x1 = cadd_mi(t1, u1);
+    x6 = cadd_pi(t1, u1);
+    x2 = cadd_mi(t2, u2);
+    x5 = cadd_pi(t2, u2);
+    x3 = cadd_mi(t3, u3);
+    x4 = cadd_pi(t3, u3);
+}
+
 // Composite radices (12, 15, 16, 20, 24, 25, 32, ...): a natural-order in-register DFT built from the
 // radix-2/3/4/5 kernels, R = Ra Rb: Rb transforms of length Ra over the strided sub-sequences, constant
 // twiddles W_R^(n2 k1) (folded at compile time), Ra transforms of length Rb (recursively).  Two LDS stages
@@ -146,10 +169,12 @@ __device__ __forceinline__ void dft_nat(float2* v) {
         dft4(v[0], v[1], v[2], v[3]);
     } else if constexpr (R == 5) {
         dft5(v[0], v[1], v[2], v[3], v[4]);
+    } else if constexpr (R == 7) {
+        dft7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
     } else {
-        constexpr int Ra = (R % 5 == 0) ? 5 : (R % 4 == 0) ? 4 : (R % 3 == 0) ? 3 : 2;
+        constexpr int Ra = (R % 7 == 0) ? 7 : (R % 5 == 0) ? 5 : (R % 4 == 0) ? 4 : (R % 3 == 0) ? 3 : 2;
         constexpr int Rb = R / Ra;
-        static_assert(Ra * Rb == R && Rb > 1, "radix must be 2-3-5 smooth");
+        static_assert(Ra * Rb == R && Rb > 1, "radix must be 2-3-5-7 smooth");
         float2 y[R];
 #pragma unroll
         for (int n2 = 0; n2 < Rb; ++n2) {
@@ -255,6 +280,7 @@ __device__ __forceinline__ void dif_stage(float2* tile, const float2* tw, int L,
         if constexpr (R == 4) dft4(v[0], v[1], v[2], v[3]);
         if constexpr (R == 5) dft5(v[0], v[1], v[2], v[3], v[4]);
         if constexpr (R == 6) dft6(v);
+        if constexpr (R == 7) dft7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
         if constexpr (R == 8) dft8(v);
         if constexpr (R == 10) dft10(v);
         if constexpr (R > 10) dft_nat<R>(v);
@@ -397,6 +423,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_pass(FftPassDev d, LoadOp load
             case 4: dif_stage<4>(tile, tw, L, mt, swz); break;
             case 5: dif_stage<5>(tile, tw, L, mt, swz); break;
             case 6: dif_stage<6>(tile, tw, L, mt, swz); break;
+            case 7: dif_stage<7>(tile, tw, L, mt, swz); break;
             case 8: dif_stage<8>(tile, tw, L, mt, swz); break;
             case 12: dif_stage<12>(tile, tw, L, mt, swz); break;
             case 15: dif_stage<15>(tile, tw, L, mt, swz); break;
@@ -1554,7 +1581,14 @@ namespace fftk {
 #define RCFM_FFT_LONG_TABLE(X) X(480, 24, 20, 1, 1) X(500, 25, 20, 1, 1)
 // Big tiles (fft_engine.h, kFftBigL): one 1024-thread workgroup per CU.  Two stages of radix 24..32 leave
 // 60 % of the 1024 threads idle and measured slower here (3.1 vs 2.75 ms at N = 2.4e8).
-#define RCFM_FFT_BIG_LENGTHS(X) X(600, 10, 10, 6, 1) X(625, 5, 5, 5, 5) X(640, 10, 8, 8, 1)
+#ifndef RCFM_R640
+#define RCFM_R640 10, 8, 8, 1
+#endif
+#ifndef RCFM_R600
+#define RCFM_R600 10, 10, 6, 1
+#endif
+#define RCFM_FFT_BIG_X_(X, LEN, ...) X(LEN, __VA_ARGS__)
+#define RCFM_FFT_BIG_LENGTHS(X) RCFM_FFT_BIG_X_(X, 600, RCFM_R600) X(625, 5, 5, 5, 5) RCFM_FFT_BIG_X_(X, 640, RCFM_R640)
 // Two stages wherever both keep at least ~60 % of the threads on a butterfly (L / R >= 10 rows of 16 lanes
 // for 256 threads, >= 19 for 512); 125 as 25 x 5 (5 rows) measured 4 % slower on cfg5.
 #define RCFM_FFT_LENGTHS_(X, LONGT) \

@@ -128,6 +128,24 @@ def wbfm_cases(impl, g, sizes=((60000, 12000), (240000, 48000), (256000, 32000))
     return out
 
 
+GEO_44100_CASES = (("WBFM", 240000, 44100), ("WBFM", 250000, 48000), ("MFM", 250000, 48000), ("MFM", 240000, 44100))
+
+
+def geo_44100_cases(impl, g):
+    """tests/golden/wbfm_44100.npz (make_golden_44100.py): CD-rate audio (44 100 = 2^2 3^2 5^2 7^2) and the reference's
+    single-station geometry 250 000 -> 48 000 (examples/receive_fm.py:18-19), two buffers each."""
+    out = []
+    for kind, B, A in GEO_44100_CASES:
+        d = getattr(impl, kind)(B, A)
+        for k in range(2):
+            x = workloads.single_channel(B, i=6 + k, stereo=(kind == "WBFM"))
+            g.check_input("in_%s%d_%d_%d" % (kind.lower(), k, B, A), x)
+            y = _asnp(d.run(x))
+            assert y.shape == ((1, A, 2) if kind == "WBFM" else (A, 1)) and y.dtype == np.float32
+            out.append(("%s buf%d %d->%d" % (kind, k, B, A), rel_err(y, g["%s%d_%d_%d" % (kind.lower(), k, B, A)])))
+    return out
+
+
 def wbfm_illcond_case(impl, g):
     """Station 5 at 60 kHz: min|z| / max|z| = 7.7e-5 at the last sample, so the
     normalised 38 kHz carrier there moves by ~1e4 x the rounding error of z."""

@@ -20,7 +20,7 @@ def test_lengths_of_the_hot_path_are_planned():
             prod *= p.L
             r = 1
             for s in range(p.nstages):
-                assert p.radix[s] in (2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 24, 25, 32)   # 20..32: in-register composites
+                assert p.radix[s] in (2, 3, 4, 5, 6, 7, 8, 10, 12, 15, 16, 20, 24, 25, 32)   # 20..32: in-register composites
                 r *= p.radix[s]
             # up to 512 points in ordinary tiles; the big tiles (600 / 625 / 640 points, two 1024-thread workgroups per
             # CU) only in three-pass plans: where they save a fourth pass (2.4e8) or beat two 500-point passes (1e8)
@@ -31,7 +31,7 @@ def test_lengths_of_the_hot_path_are_planned():
     assert [fft_model.describe(240_000).passes[t].L for t in range(2)] == [480, 500]
 
 
-@pytest.mark.parametrize("n", [100, 24001, 7 * 4096, 255])
+@pytest.mark.parametrize("n", [100, 24001, 11 * 4096, 255])
 def test_unsupported_lengths_are_refused(n):
     assert fft_model.describe(n) is None
 
@@ -40,6 +40,21 @@ def test_unsupported_lengths_are_refused(n):
 def test_model_of_the_plan_is_an_fft(n):
     plan = fft_model.describe(n)
     assert plan is not None
+    r = np.random.default_rng(n)
+    x = r.standard_normal(n) + 1j * r.standard_normal(n)
+    got = fft_model.model_fft(x, plan)
+    want = np.fft.fft(x)
+    assert np.max(np.abs(got - want)) <= 1e-9 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("n", [44100, 88200, 22050, 7 * 4096, 33600, 7 ** 4 * 16])
+def test_lengths_with_a_factor_seven(n):
+    """Round 6: a radix-7 butterfly in the generic tile kernel keeps audio rates like 44 100 = 210 x 210 inside the
+    engine (before, such a length sent every demodulator transform to rocFFT: 2.6 x the channel stages of 48 000,
+    bench.py other_configs.path_map)."""
+    plan = fft_model.describe(n)
+    assert plan is not None and plan.npass == 2
+    assert any(plan.passes[t].radix[s] == 7 for t in range(plan.npass) for s in range(plan.passes[t].nstages))
     r = np.random.default_rng(n)
     x = r.standard_normal(n) + 1j * r.standard_normal(n)
     got = fft_model.model_fft(x, plan)

@@ -527,11 +527,11 @@ def test_path_map_cells_against_the_oracle(rc, oracle, B, A):
     finally:
         hip.check(lib.rcfm_profile_enable(0))
     print("path_map cell", B, A, {k: v for k, v in ran.items() if v})
-    smooth = A % 7 != 0                               # 44 100 = 2^2 3^2 5^2 7^2
-    if smooth:
-        assert ran["hilbert_mask"] == 0, ran          # {2,3,5}-smooth: never the rocFFT route
-    else:
-        assert ran["hilbert_mask"] > 0 and ran["stereo_mix"] > 0, ran
+    # never the rocFFT route (hilbert_mask / stereo_mix are stages of that route only): 44 100 = 2^2 3^2 5^2 7^2 runs the
+    # fused pilot chain and its A-point transforms through the engine's radix-7 butterfly since round 6
+    assert ran["hilbert_mask"] == 0 and ran["stereo_mix"] == 0, ran
+    if A % 7 == 0:
+        assert ran["ifft_A"] > 0, ran                 # 480 does not divide 44 100: no decimating tile, a separate IFFT_A
 
 
 @pytest.mark.parametrize("narrow", [0, 2])

@@ -37,6 +37,19 @@ def test_engine_matches_numpy(n, batch, inverse):
         assert rel_err(_run(n, batch, inverse, x, in_place=True), want.astype(np.complex64)) <= 2e-6
 
 
+@pytest.mark.parametrize("n,batch", [(44100, 3), (88200, 2), (22050, 1), (7 * 4096, 2), (33600, 2), (7 ** 4 * 16, 1), (441000, 1)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_lengths_with_a_factor_seven(n, batch, inverse):
+    """The radix-7 butterfly of the generic tile kernel (k_fft_pass): 44 100 = 210 x 210 and its neighbours, 7^4 x 16
+    (radix 7 in consecutive stages), a three-pass length -- against numpy, forward and inverse, out of place and in place."""
+    r = np.random.default_rng(n + batch)
+    x = (r.standard_normal((batch, n)) + 1j * r.standard_normal((batch, n))).astype(np.complex64)
+    want = np.fft.ifft(x.astype(np.complex128), axis=1) * n if inverse else np.fft.fft(x.astype(np.complex128), axis=1)
+    assert rel_err(_run(n, batch, inverse, x), want.astype(np.complex64)) <= 2e-6
+    if n <= 88200:
+        assert rel_err(_run(n, batch, inverse, x, in_place=True), want.astype(np.complex64)) <= 2e-6
+
+
 @pytest.mark.parametrize("n", [24000, 49152, 96000, 144000, 204800])
 def test_every_specialised_tile_length(n):
     """The remaining tile lengths with a compile-time kernel (150/160, 192/256, 300/320, 375/384, 400/512),

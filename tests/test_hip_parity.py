@@ -78,6 +78,12 @@ def test_golden_wbfm(rc, golden):
     _check(gc.wbfm_cases(rc, golden("wbfm")))
 
 
+def test_golden_cd_rate_audio_and_the_reference_example_geometry(rc, golden):
+    """240 000 -> 44 100 (every A-point transform through the engine's radix-7 butterfly) and 250 000 -> 48 000
+    (examples/receive_fm.py:18-19), WBFM and MFM, against outputs of the reference itself."""
+    _check(gc.geo_44100_cases(rc, golden("wbfm_44100")))
+
+
 def test_golden_wbfm_ill_conditioned(rc, golden):
     # see tests/golden_cases.py: conditioning ~1.3e4 at one sample
     _check(gc.wbfm_illcond_case(rc, golden("wbfm")), tol=1e-3)

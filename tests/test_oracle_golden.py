@@ -48,6 +48,10 @@ def test_wbfm(golden):
     _check(gc.wbfm_cases(oracle, golden("wbfm")))
 
 
+def test_cd_rate_audio_and_the_reference_example_geometry(golden):
+    _check(gc.geo_44100_cases(oracle, golden("wbfm_44100")))
+
+
 def test_wbfm_ill_conditioned(golden):
     # rounding in z (2e-7 of peak) x conditioning (1.3e4) / decimation smoothing
     _check(gc.wbfm_illcond_case(oracle, golden("wbfm")), tol=1e-3)
