@@ -98,11 +98,6 @@ struct FftPassDev {
     float fine_step;          // 2 pi / n
     int fine_bits;
     int64_t in_batch, out_batch;
-    // Experiment build -DRCFM_TW_TABLE=1 (profiles/r06_*_twiddle_table.md): the inter-pass twiddles of a two-pass plan's first
-    // pass as a full table, tw_full[k * n_inner + i] = W_n^(i k) -- one 8-byte load per output (lanes along i: whole
-    // 128-byte segments, 8 n bytes per plan that stay in the L2s) instead of a coarse-table entry + series per butterfly and
-    // a running product per output.  nullptr: computed (the default build never sets it).
-    const float2* tw_full = nullptr;
 };
 
 // Rows of the transform's output to keep (row r = output elements [r n_1, (r+1) n_1), n_1 = the plan's first
@@ -145,8 +140,6 @@ class FftEngine {
     static size_t lds_bytes(int L);
     static dim3 grid(const FftPass& p, int batch);
     static int compute_units();   // CUs of the current device (256 on MI355X)
-    // -DRCFM_TW_TABLE experiment: builds the full inter-pass twiddle table of pass 0 (two-pass plans); pass_dev(0, ...) carries it
-    void enable_twiddle_table() const;
 
    private:
     void build_tables();
@@ -157,7 +150,6 @@ class FftEngine {
     DeviceBuffer stage_tw_[kFftMaxPasses];
     DeviceBuffer pos_[kFftMaxPasses];
     DeviceBuffer coarse_;
-    mutable DeviceBuffer tw_full_;
 };
 
 }  // namespace rcfm

@@ -405,21 +405,7 @@ FftPassDev FftEngine::pass_dev(int t, int64_t in_batch, int64_t out_batch, bool 
     d.fine_bits = desc_.fine_bits;
     d.in_batch = in_batch;
     d.out_batch = out_batch;
-    d.tw_full = (t == 0 && tw_full_.bytes() != 0) ? tw_full_.as<float2>() : nullptr;
     return d;
-}
-
-void FftEngine::enable_twiddle_table() const {
-    if (tw_full_.bytes() != 0 || desc_.npass != 2) return;
-    const FftPass& p = desc_.pass[0];
-    const int64_t n = desc_.n;
-    std::vector<float2> tw((size_t)p.L * (size_t)p.n_inner);
-    for (int64_t k = 0; k < p.L; ++k)
-        for (int64_t i = 0; i < p.n_inner; ++i) {
-            const double a = -kTwoPi * (double)((i * p.tw_i * k) % n) / (double)n;
-            tw[(size_t)(k * p.n_inner + i)] = make_float2((float)std::cos(a), (float)std::sin(a));
-        }
-    tw_full_.upload(tw.data(), tw.size() * sizeof(float2));
 }
 
 void FftEngine::c2c(const float2* in, float2* out, float2* tmp, int batch, bool inverse, float scale,

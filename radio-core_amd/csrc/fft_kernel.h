@@ -1025,24 +1025,6 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
     }
     lds_barrier();
 
-#if defined(RCFM_TW_TABLE) && RCFM_TW_TABLE
-    // experiment: the inter-pass twiddle of every output this thread will store, fetched now (L2 hits) and consumed after
-    // the second transform's stages
-    float2 twv[nitL * RL];
-    {
-        const float2* twt = d2.tw_full + (i0 + (w < wvalid ? w : 0));
-        const unsigned tw_pitch = (unsigned)p2.n_inner;
-#pragma unroll
-        for (int it = 0; it < nitL; ++it) {
-            int g = rg + RG * it;
-            if (rowsL % RG != 0) g = g < rowsL ? g : 0;
-            const int kb = kbase(g);
-#pragma unroll
-            for (int q = 0; q < RL; ++q) twv[it * RL + q] = twt[(unsigned)(kb + (L / RL) * q) * tw_pitch];
-        }
-    }
-#endif
-
     // ---- second transform: a strided pass of plan 2 whose input already sits in LDS ----------
     stage_lds<L, R0, L, true, RG, true, false, kZeroQ>(tile, tw, w, rg);
     lds_barrier();
@@ -1055,26 +1037,6 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
         lds_barrier();
     }
     const bool lane_ok = w < wvalid;
-#if defined(RCFM_TW_TABLE) && RCFM_TW_TABLE
-#pragma unroll
-    for (int it = 0; it < nitL; ++it) {
-        const int g = rg + RG * it;
-        if ((rowsL % RG == 0) || g < rowsL) {
-            float2 x[RL];
-#pragma unroll
-            for (int q = 0; q < RL; ++q) x[q] = tile[lds_slot<true>(g * RL + q, w)];
-            dft_p<RL>(x);
-            const int kb = kbase(g);
-            if (lane_ok) {
-#pragma unroll
-                for (int q = 0; q < RL; ++q) {
-                    const int k = kb + (L / RL) * q;
-                    store(id, k, out_base, (unsigned)k * out_k + (unsigned)w, cmul(x[dft_slot<RL>(q)], twv[it * RL + q]));
-                }
-            }
-        }
-    }
-#else
     const unsigned f = (unsigned)((int64_t)(i0 + w) * p2.tw_i);
     const float2 D = big_twiddle(d2, f * (unsigned)(L / RL));
 #pragma unroll
@@ -1098,7 +1060,6 @@ __global__ __launch_bounds__(T, (T * 16 / W >= 512 ? 4 : 1)) void k_fft_tile2(Ff
             }
         }
     }
-#endif
 }
 
 // ---- one inverse transform in, two forward transforms out ------------------------------

@@ -722,9 +722,6 @@ void fused_pilot_chain_mask_mix(const FftEngine& ef, const FftEngine& ei, const 
     const int64_t n = ef.desc().n;
     const int pairs = (count + 1) / 2;
     {   // pair FFT last pass -> mask -> inverse FFT first pass: the pair spectrum never reaches memory
-#if defined(RCFM_TW_TABLE) && RCFM_TW_TABLE
-        ei.enable_twiddle_table();
-#endif
         const FftPassDev d1 = ef.pass_dev(1, ef.tmp_stride(), n);
         const FftPassDev d2 = ei.pass_dev(0, n, ei.tmp_stride());
         fftk::LoadPlainT<false> ld{tmp_f};

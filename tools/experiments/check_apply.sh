@@ -14,6 +14,7 @@ declare -A BASES=(
   [r04_narrow_tiles_per_stage.patch]=a2261f836d1f
   [r05_quad_plan.patch]=bf38dd2dfbd0
   [r05_wave_owned_mask_tile.patch]=f9b41baa5aab
+  [r06_big_tile_probes.patch]=c2c60cbfe553
 )
 bad=0
 wt=$(mktemp -d /tmp/rcfm_patch_check.XXXXXX)
