@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off regression sweep of the FFT engine (GPU box): random {2,3,5}-smooth lengths and batches against numpy.fft.
+"""One-off regression sweep of the FFT engine (GPU box): random {2,3,5,7}-smooth lengths and batches against numpy.fft.
     python tools/fuzz_fft.py [count] [seed]"""
 import os
 import sys
@@ -17,7 +17,7 @@ def smooth(rng, lo=256, hi=4_000_000):
         n = 1
         target = int(np.exp(rng.uniform(np.log(lo), np.log(hi))))
         while n < target:
-            n *= int(rng.choice([2, 2, 3, 5, 5]))
+            n *= int(rng.choice([2, 2, 2, 3, 3, 5, 5, 5, 7]))
         if lo <= n <= hi:
             return n
 

@@ -21,12 +21,12 @@ def rel(a, b):
 def main(count=40, seed=3):
     rng = np.random.default_rng(seed)
     Bs = [24000, 25000, 30000, 32000, 36000, 40000, 48000, 50000, 60000, 64000, 75000, 80000, 96000, 100000,
-          24001, 30030, 46000, 62500, 65536, 12500, 12500, 12000, 10000]      # (the last three: LDS-resident chain with A = 8000 / 6250)
+          24001, 30030, 46000, 62500, 65536, 12500, 12500, 12000, 10000, 44100, 88200, 56000, 49000]      # (the last three: LDS-resident chain with A = 8000 / 6250)
     worst = 0.0
     for i in range(count):
         B = int(rng.choice(Bs))
         kind = str(rng.choice(["FM", "MFM", "WBFM"]))
-        A = int(rng.choice([B // 5, B // 4, B // 2, B // 3 + 1, 8000, 8000, 6250, 12000, 16000, 9999] if kind != "WBFM" else [B // 5, B // 4, B // 2, 12000, 16000]))
+        A = int(rng.choice([B // 5, B // 4, B // 2, B // 3 + 1, 8000, 8000, 6250, 12000, 16000, 9999, 11025, 22050] if kind != "WBFM" else [B // 5, B // 4, B // 2, 12000, 16000, 22050, 11025]))
         A = max(A, 300)
         if kind == "WBFM" and (B < 45000 or B % 2):
             B = 60000                                   # the 19 kHz pilot band-pass needs the rate; keep even sizes
