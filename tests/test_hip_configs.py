@@ -562,3 +562,48 @@ def test_run_all_with_both_tile_widths(rc, oracle, kind, B, A, narrow):
         for c in ref.channels():
             want = np.asarray(c.demodulator.run(ref.run_pruned(c.index))).reshape(A, ch)
             assert rel_err(audio[c.index], want) <= TOL, (kind, B, A, narrow, buf, c.index, rel_err(audio[c.index], want))
+
+
+def test_cfg4_shards_reproduce_the_whole_band_bit_for_bit_under_both_wideband_plans():
+    """What bench.py's N > 1 `self_check` relies on, on ONE GPU at cfg4's full size: a rank that declares an eighth of
+    the channels (rcfm_tuner_shard: a row window of the wideband FFT's last pass) and runs only those computes exactly
+    the audio a one-GPU run of all 1024 channels computes for them -- with the handle's default wideband plan (the aligned
+    order in the padded-rows layout: what the replicated partitioning runs) and with RCFM_TUNER_OPT_ALIGNED_PLAN = 0 (the
+    default order: what a rotating owner runs into an attached slot).  The two plans differ from each other in rounding
+    only (<= 2e-6 of peak), which is why bench.py keeps one reference per plan."""
+    import torch
+    import bench
+    import workloads_device
+    from radiocore._internal import hip
+    lib = hip.lib()
+    N, C, B, A, raster, kind = bench.CONFIGS["cfg4"]
+    x, centres, f_in = workloads_device.synth_wideband_on_device(N, C, B, raster, kind, lib, hip)
+    rolls = (ctypes.c_int64 * C)(*[int(f_in - f) for f in centres])
+    bws = (ctypes.c_int32 * C)(*([B] * C))
+    s = hip.stream()
+
+    def run(aligned, lo, cnt):
+        t, d = ctypes.c_void_p(), ctypes.c_void_p()
+        hip.check(lib.rcfm_tuner_create(N, C, rolls, bws, ctypes.byref(t)))
+        hip.check(lib.rcfm_tuner_set_option(t, hip.RCFM_TUNER_OPT_ALIGNED_PLAN, aligned))
+        hip.check(lib.rcfm_tuner_shard(t, lo, cnt))
+        hip.check(lib.rcfm_demod_create(2, C, B, A, ctypes.c_double(75e-6), 0, ctypes.byref(d)))
+        audio = torch.empty((cnt, A, 2), dtype=torch.float32, device="cuda")
+        hip.check(lib.rcfm_tuner_load(t, hip.ptr(x), s))
+        hip.check(lib.rcfm_pipeline_run(t, d, lo, cnt, hip.ptr(audio), s))
+        torch.cuda.synchronize()
+        hip.check(lib.rcfm_demod_destroy(d))
+        hip.check(lib.rcfm_tuner_destroy(t))
+        return audio
+
+    whole = {}
+    for aligned in (1, 0):
+        whole[aligned] = run(aligned, 0, C)
+        assert float(whole[aligned].abs().amax()) > 1e-3
+        for lo in (0, 384, 896):                    # first, a middle and the last eighth (the band's ends wrap)
+            part = run(aligned, lo, 128)
+            assert torch.equal(part, whole[aligned][lo:lo + 128]), (aligned, lo)
+            del part
+    peak = float(whole[1].abs().amax())
+    diff = float((whole[1] - whole[0]).abs().amax())
+    assert diff <= 2e-5 * peak, (diff, peak)      # same transform, another order of the passes: rounding only
