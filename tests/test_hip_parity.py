@@ -494,3 +494,26 @@ def test_server_loop_example(rc, oracle):
     assert len(msgs2) == len(msgs)
     for (f1, a1), (f2, a2) in zip(msgs, msgs2):
         assert f1 == f2 and np.array_equal(a1, a2)
+
+
+@pytest.mark.parametrize("kind", ["WBFM", "MFM"])
+def test_single_station_example(rc, oracle, kind):
+    """examples/receive_fm_offline.py = the reference's examples/receive_fm.py without SDR and sound card: producer thread
+    -> RingBuffer -> complex Decimate(10 000 000 -> 250 000) -> WBFM / MFM(250 000 -> 48 000), the reference's own default
+    geometry (receive_fm.py:15-21), two seconds (de-emphasis state): every audio block equals the oracle's."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("receive_fm_offline", os.path.join(ROOT, "examples", "receive_fm_offline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seconds, n, b, a = 2, 10_000_000, 250_000, 48_000
+    got = mod.run(seconds, kind, n, b, a)
+    assert len(got) == seconds
+    decim = oracle.Decimate(n, b)
+    demod = getattr(oracle, kind)(b, a)
+    for s in range(seconds):
+        x = mod.capture(n, b, stereo=(kind == "WBFM"), second=s)
+        want = np.asarray(demod.run(decim.run(x)))
+        assert got[s].shape == want.shape == ((1, a, 2) if kind == "WBFM" else (a, 1))
+        assert rel_err(got[s], want) <= TOL, (kind, s, rel_err(got[s], want))
