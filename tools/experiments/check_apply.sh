@@ -16,6 +16,7 @@ declare -A BASES=(
   [r05_wave_owned_mask_tile.patch]=f9b41baa5aab
   [r06_big_tile_probes.patch]=c2c60cbfe553
   [r06_twiddle_table.patch]=7118f5dd8967
+  [r06_fir_state_merge.patch]=dd4b3e5a84e6
 )
 bad=0
 wt=$(mktemp -d /tmp/rcfm_patch_check.XXXXXX)
